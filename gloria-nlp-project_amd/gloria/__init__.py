@@ -1,0 +1,4 @@
+"""gloria - MI355X-native GLoRIA pretraining hot path (drop-in for the reference package's
+`gloria.builder` / `gloria.lightning.PretrainModel` / `gloria.loss.gloria_loss` surface)."""
+
+from . import loss  # noqa: F401

@@ -1,0 +1,129 @@
+"""ctypes binding of libglr.so (C ABI: include/glr.h).
+
+The product path has NO fallback: if the HIP library is missing or a call fails, a
+RuntimeError is raised.  torch is used only for device memory and the current stream.
+"""
+
+import ctypes
+import os
+from ctypes import c_float, c_int, c_int64, c_void_p, POINTER
+
+import numpy as np
+import torch
+
+GLR_F32, GLR_BF16 = 0, 1
+AGG = {"sum": 0, "mean": 1, "max": 2}
+TILE_WORDS = 64
+MAX_SPAD = 384
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.normpath(os.path.join(_HERE, "..", "lib", "libglr.so"))
+
+SYMBOLS = {
+    # name: (restype, argtypes)
+    "glr_version": (c_int, []),
+    "glr_region_pad": (c_int, [c_int]),
+    "glr_plan_tiles_bound": (c_int, [c_void_p, c_int]),
+    "glr_plan_tiles": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "glr_pack_regions": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "glr_pack_words": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                               c_int, c_int, c_void_p]),
+    "glr_local_attn_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                   c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_float, c_float, c_int,
+                                   c_float, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int,
+                                   c_int, c_int, c_void_p]),
+    "glr_dual_ce_fwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "glr_dual_ce_bwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "glr_global_sim_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float, c_void_p, c_int,
+                                   c_void_p, c_void_p, c_void_p]),
+    "glr_global_sim_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                   c_float, c_float, c_void_p, c_void_p, c_void_p]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load libglr.so (once).  Raises if it has not been built: there is no CPU path."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: the GLoRIA hot path needs the HIP library "
+                "(build it with `python -c 'import __graft_entry__ as g; g.build()'` or `make -C csrc`)")
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(handle, name)          # AttributeError if the ABI is incomplete
+            fn.restype, fn.argtypes = res, args
+        _lib = handle
+    return _lib
+
+
+def check(code, what):
+    if code != 0:
+        raise RuntimeError(f"libglr: {what} failed with code {code}")
+
+
+def dtype_code(dt):
+    if dt == torch.float32:
+        return GLR_F32
+    if dt == torch.bfloat16:
+        return GLR_BF16
+    raise TypeError(f"libglr supports float32 and bfloat16 tensors, got {dt}")
+
+
+def torch_dtype(code):
+    return torch.float32 if code == GLR_F32 else torch.bfloat16
+
+
+def ptr(t):
+    return None if t is None else c_void_p(t.data_ptr())
+
+
+def stream():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("the GLoRIA hot path runs on the GPU only (HIP kernels); got a CPU tensor")
+
+
+class TilePlan:
+    """Sentence -> word-slot packing (host planning by glr_plan_tiles + device copies)."""
+
+    def __init__(self, cap_lens, device):
+        cl = np.ascontiguousarray(np.asarray(cap_lens, dtype=np.int32))
+        n = int(cl.shape[0])
+        L = lib()
+        bound = L.glr_plan_tiles_bound(cl.ctypes.data_as(c_void_p), n)
+        if bound <= 0:
+            raise ValueError(f"cap_lens must be in [1, 512] (glr_plan_tiles_bound -> {bound})")
+        slot0 = np.zeros(n, dtype=np.int32)
+        tile_first = np.zeros(bound + 1, dtype=np.int32)
+        order = np.zeros(bound, dtype=np.int32)
+        nsub = np.zeros(bound, dtype=np.int32)
+        nt = L.glr_plan_tiles(cl.ctypes.data_as(c_void_p), n, slot0.ctypes.data_as(c_void_p),
+                              tile_first.ctypes.data_as(c_void_p), order.ctypes.data_as(c_void_p),
+                              nsub.ctypes.data_as(c_void_p))
+        if nt <= 0:
+            raise ValueError(f"glr_plan_tiles failed ({nt})")
+        self.cap_lens_host = cl
+        self.n_sent, self.n_tiles, self.n_slots = n, nt, nt * TILE_WORDS
+        self.sent_slot0_host = slot0
+        self.n_words = int(cl.sum())
+        pack = np.concatenate([cl, slot0, tile_first[: nt + 1], order, nsub[:nt]]).astype(np.int32)
+        dev = torch.from_numpy(pack).to(device, non_blocking=True)
+        o = 0
+        self.cap_lens = dev[o:o + n]; o += n
+        self.sent_slot0 = dev[o:o + n]; o += n
+        self.tile_first = dev[o:o + nt + 1]; o += nt + 1
+        self.order = dev[o:o + bound]; o += bound
+        self.tile_nsub = dev[o:o + nt]
+        self._dev = dev
+
+    def attn_offsets(self, s_out, device):
+        off = np.zeros(self.n_sent + 1, dtype=np.int64)
+        np.cumsum(self.cap_lens_host.astype(np.int64) * s_out, out=off[1:])
+        return torch.from_numpy(off[:-1].copy()).to(device), off

@@ -1,0 +1,332 @@
+"""MI355X-native `gloria.loss.gloria_loss`: same names, arguments, return tuples and error
+behaviour as /root/reference/gloria/loss/gloria_loss.py, computed by the hand-written HIP
+kernels of libglr.so (include/glr.h) instead of a Python loop over sentences.
+
+    cosine_similarity  (ref :11-16)      attention_fn (ref :19-63)
+    global_loss        (ref :66-88)      local_loss   (ref :99-201)
+
+Differences that are deliberate and documented in DESIGN.md:
+  * GPU only.  CPU tensors raise: there is no CPU or eager fallback for the forward.
+  * fp32 inputs run the fp32-MFMA kernels (the 1e-4 parity mode); bf16 inputs (autocast) run the
+    bf16-MFMA kernels with fp32 accumulation / softmax / log / exp.  `set_compute_dtype` can force
+    bf16 operands for fp32 inputs.
+  * `local_loss` forms the whole B x B similarity matrix in ONE launch; nothing of size
+    O(B * |img_features|) is kept for backward (the reference keeps one transposed copy per
+    sentence).
+"""
+
+from typing import List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from .. import _native as N
+from . import _recompute as R
+
+_COMPUTE_DTYPE = None          # None = follow the input dtype
+
+
+def set_compute_dtype(dtype: Optional[torch.dtype]):
+    """Force the MFMA operand dtype (torch.float32 / torch.bfloat16) or None to follow inputs."""
+    global _COMPUTE_DTYPE
+    if dtype not in (None, torch.float32, torch.bfloat16):
+        raise TypeError("compute dtype must be float32, bfloat16 or None")
+    _COMPUTE_DTYPE = dtype
+
+
+def _op_code(*tensors):
+    if _COMPUTE_DTYPE is not None:
+        return N.dtype_code(_COMPUTE_DTYPE)
+    return N.GLR_BF16 if any(t.dtype == torch.bfloat16 for t in tensors) else N.GLR_F32
+
+
+def _as_supported(t):
+    if t.dtype in (torch.float32, torch.bfloat16):
+        return t.contiguous()
+    return t.float().contiguous()      # fp16 / fp64 inputs are computed in fp32
+
+
+# ------------------------------------------------------------------------------------------
+# fused local similarity (K1) as an autograd function
+# ------------------------------------------------------------------------------------------
+
+class _Opts:
+    def __init__(self, temp1, temp2, temp3, agg, eps, want_attn, img_offset, word_start, pair_only, want_wctx):
+        self.temp1, self.temp2, self.temp3 = float(temp1), float(temp2), float(temp3)
+        self.agg, self.eps = agg, float(eps)
+        self.want_attn, self.img_offset, self.word_start = want_attn, int(img_offset), int(word_start)
+        self.pair_only, self.want_wctx = pair_only, want_wctx
+
+
+def _launch_local(img3, words, no_attn_vec, plan, o):
+    """img3 [B, D, S], words [B_txt, D, L] on the GPU.  Returns sim, attn_flat, wctx."""
+    L = N.lib()
+    dev = img3.device
+    B, D, S = img3.shape
+    shift = 0 if no_attn_vec is None else 1
+    s_eff = S + shift
+    s_pad = L.glr_region_pad(s_eff)
+    if s_pad > N.MAX_SPAD:
+        raise ValueError(f"{s_eff} regions exceed the kernel limit of {N.MAX_SPAD}")
+    if D % 64 != 0:
+        raise ValueError(f"embedding dim must be a multiple of 64, got {D}")
+    code = _op_code(img3, words)
+    odt = N.torch_dtype(code)
+    in_code = N.dtype_code(img3.dtype)
+    if words.dtype != img3.dtype:
+        words = words.to(img3.dtype)
+    na = None if no_attn_vec is None else no_attn_vec.detach().to(img3.dtype).contiguous()
+    st = N.stream()
+    vt = torch.empty(B, s_pad, D, dtype=odt, device=dev)
+    vd = torch.empty(B, D, s_pad, dtype=odt, device=dev)
+    N.check(L.glr_pack_regions(N.ptr(img3), in_code, N.ptr(na), N.ptr(vt), N.ptr(vd), B, D, S, code, st),
+            "glr_pack_regions")
+    tp = torch.empty(plan.n_slots, D, dtype=odt, device=dev)
+    tnorm = torch.empty(plan.n_slots, dtype=torch.float32, device=dev)
+    N.check(L.glr_pack_words(N.ptr(words), in_code, N.ptr(plan.sent_slot0), N.ptr(plan.cap_lens), N.ptr(tp),
+                             N.ptr(tnorm), words.shape[0], D, words.shape[2], o.word_start, plan.n_slots, code, st),
+            "glr_pack_words")
+    n_sent = plan.n_sent
+    sim = (torch.zeros if o.pair_only else torch.empty)(B, n_sent, dtype=torch.float32, device=dev)
+    attn = attn_off = None
+    s_out = s_eff - shift
+    if o.want_attn:
+        attn_off, off_host = plan.attn_offsets(s_out, dev)
+        attn = torch.zeros(int(off_host[-1]), dtype=torch.float32, device=dev)
+    wctx, ld_wctx = None, 0
+    if o.want_wctx:
+        ld_wctx = int(plan.cap_lens_host.max())
+        wctx = torch.zeros(B, D, ld_wctx, dtype=torch.float32, device=dev)
+    N.check(L.glr_local_attn_fwd(N.ptr(vt), N.ptr(vd), N.ptr(tp), N.ptr(tnorm), N.ptr(plan.sent_slot0),
+                                 N.ptr(plan.cap_lens), N.ptr(plan.tile_first), N.ptr(plan.order),
+                                 N.ptr(plan.tile_nsub), plan.n_tiles, n_sent, B, D, s_eff, o.temp1, o.temp2,
+                                 o.temp3, N.AGG[o.agg], o.eps, N.ptr(sim), n_sent, N.ptr(attn), N.ptr(attn_off),
+                                 shift, N.ptr(wctx), ld_wctx, 1 if o.pair_only else 0, o.img_offset, code, st),
+            "glr_local_attn_fwd")
+    return sim, attn, wctx
+
+
+class LocalSimFn(torch.autograd.Function):
+    """sim[b, i] for local images x all sentences (+ diagonal attention maps), HIP forward."""
+
+    @staticmethod
+    def forward(ctx, img_features, words_emb, no_attn_vec, plan, opts):
+        N.require_cuda(img_features, words_emb, no_attn_vec)
+        B, D = img_features.shape[:2]
+        img3 = _as_supported(img_features.detach()).reshape(B, D, -1)
+        words = _as_supported(words_emb.detach())
+        sim, attn, wctx = _launch_local(img3, words, no_attn_vec, plan, opts)
+        ctx.save_for_backward(img_features, words_emb, no_attn_vec)
+        ctx.plan, ctx.opts = plan, opts
+        ctx.set_materialize_grads(False)       # unused outputs (maps, context) arrive as None
+        if attn is None:
+            attn = sim.new_zeros(0)
+        if wctx is None:
+            wctx = sim.new_zeros(0)
+        return sim, attn, wctx
+
+    @staticmethod
+    def backward(ctx, dsim, dattn, dwctx):
+        img_features, words_emb, no_attn_vec = ctx.saved_tensors
+        plan, o = ctx.plan, ctx.opts
+        dev = img_features.device
+        B, D = img_features.shape[:2]
+        img = img_features.detach().float().reshape(B, D, -1)
+        words = words_emb.detach().float().requires_grad_(True)
+        na = None if no_attn_vec is None else no_attn_vec.detach().float().requires_grad_(True)
+        si = torch.from_numpy(np.repeat(np.arange(plan.n_sent), plan.cap_lens_host)).to(dev)
+        wi = torch.from_numpy(np.concatenate([np.arange(n) for n in plan.cap_lens_host]) + o.word_start).to(dev)
+        capf = torch.from_numpy(plan.cap_lens_host.astype(np.float32)).to(dev)
+        d_img = torch.zeros_like(img)
+        s_eff = img.shape[2] + (0 if na is None else 1)
+        # images per chunk so that ~12 live [chunk, S, N] fp32 tensors stay near 2 GB
+        chunk = max(1, min(B, int(2e9 / (12.0 * 4 * s_eff * max(plan.n_words, 1)))))
+        need_attn = o.want_attn and dattn is not None and dattn.numel() > 0
+        need_wctx = o.want_wctx and dwctx is not None and dwctx.numel() > 0
+        with torch.enable_grad():
+            T = words.permute(0, 2, 1)[si, wi]                          # [N, D]
+            if dsim is not None and not o.pair_only:
+                for b0 in range(0, B, chunk):
+                    vc = img[b0:b0 + chunk].clone().requires_grad_(True)
+                    V = vc if na is None else torch.cat([na.view(1, D, 1).expand(vc.shape[0], D, 1), vc], 2)
+                    sim_c, _ = R.local_sim_packed(V, T, si, capf, o.temp1, o.temp2, o.temp3, o.agg, o.eps)
+                    sim_c.backward(dsim[b0:b0 + chunk].float(), retain_graph=True)
+                    d_img[b0:b0 + chunk] = vc.grad
+            if need_attn or need_wctx or (dsim is not None and o.pair_only):
+                # diagonal pairs only (attention maps / attention_fn outputs): B small problems
+                vc = img.clone().requires_grad_(True)
+                V = vc if na is None else torch.cat([na.view(1, D, 1).expand(B, D, 1), vc], 2)
+                lens = plan.cap_lens_host[o.img_offset:o.img_offset + B]
+                wloc = words[o.img_offset:o.img_offset + B]
+                a2 = R.diag_attention(V, wloc, lens, o.word_start, o.temp1)     # [B, Lmax, S_eff]
+                loss = 0.0
+                shift = 0 if na is None else 1
+                if need_attn:
+                    flat = torch.cat([a2[b, :int(lens[b]), shift:].reshape(-1) for b in range(B)])
+                    off0 = int((plan.cap_lens_host[:o.img_offset].astype(np.int64) * (s_eff - shift)).sum())
+                    loss = loss + (flat * dattn[off0:off0 + flat.numel()].float()).sum()
+                if need_wctx:
+                    ctxv = torch.einsum("bdr,bwr->bdw", V, a2)                  # [B, D, Lmax]
+                    loss = loss + (ctxv * dwctx[:, :, :ctxv.shape[2]].float()).sum()
+                if torch.is_tensor(loss):
+                    loss.backward()
+                    d_img += vc.grad
+        d_words = words.grad if words.grad is not None else torch.zeros_like(words)
+        d_na = None if na is None else (na.grad if na.grad is not None else torch.zeros_like(na))
+        return (d_img.reshape(img_features.shape).to(img_features.dtype), d_words.to(words_emb.dtype),
+                None if d_na is None else d_na.to(no_attn_vec.dtype), None, None)
+
+
+# ------------------------------------------------------------------------------------------
+# dual cross entropy (K2) and global similarity (K3)
+# ------------------------------------------------------------------------------------------
+
+class DualCEFn(torch.autograd.Function):
+    """(loss0, loss1) of a full B x B matrix; gradient only for this rank's block of rows."""
+
+    @staticmethod
+    def forward(ctx, sim_rows, sim_full, row0):
+        N.require_cuda(sim_rows, sim_full)
+        L = N.lib()
+        full = sim_full.detach().float().contiguous()
+        B = full.shape[0]
+        if full.shape[1] != B:
+            raise ValueError("similarity matrix must be square")
+        lse = torch.empty(2, B, dtype=torch.float32, device=full.device)
+        losses = torch.empty(2, dtype=torch.float32, device=full.device)
+        N.check(L.glr_dual_ce_fwd(N.ptr(full), B, N.ptr(lse[0]), N.ptr(lse[1]), N.ptr(losses), N.stream()),
+                "glr_dual_ce_fwd")
+        ctx.save_for_backward(full, lse)
+        ctx.row0, ctx.n_rows = int(row0), sim_rows.shape[0]
+        return losses[0], losses[1]
+
+    @staticmethod
+    def backward(ctx, g0, g1):
+        full, lse = ctx.saved_tensors
+        B = full.shape[0]
+        g = torch.stack([g0.float() if g0 is not None else full.new_zeros(()),
+                         g1.float() if g1 is not None else full.new_zeros(())]).contiguous()
+        dsim = torch.empty(ctx.n_rows, B, dtype=torch.float32, device=full.device)
+        N.check(N.lib().glr_dual_ce_bwd(N.ptr(full), B, N.ptr(lse[0]), N.ptr(lse[1]), N.ptr(g), ctx.row0,
+                                        ctx.n_rows, N.ptr(dsim), N.stream()), "glr_dual_ce_bwd")
+        return dsim, None, None
+
+
+def dual_cross_entropy(sim_rows, sim_full=None, row0=0):
+    """CE(sim, arange) and CE(sim^T, arange) (ref :86-87, :167-170).  `sim_rows` is this process's
+    block of rows of the square matrix `sim_full` (default: the matrix itself)."""
+    if sim_full is None:
+        sim_full = sim_rows
+    return DualCEFn.apply(sim_rows, sim_full, row0)
+
+
+class GlobalSimFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, img, txt, temp3, eps):
+        N.require_cuda(img, txt)
+        L = N.lib()
+        a, t = img.detach().float().contiguous(), txt.detach().float().contiguous()
+        Bi, D = a.shape
+        Bt = t.shape[0]
+        sim = torch.empty(Bi, Bt, dtype=torch.float32, device=a.device)
+        ni = torch.empty(Bi, dtype=torch.float32, device=a.device)
+        nt = torch.empty(Bt, dtype=torch.float32, device=a.device)
+        N.check(L.glr_global_sim_fwd(N.ptr(a), N.ptr(t), Bi, Bt, D, float(temp3), float(eps), N.ptr(sim), Bt,
+                                     N.ptr(ni), N.ptr(nt), N.stream()), "glr_global_sim_fwd")
+        ctx.save_for_backward(a, t, ni, nt)
+        ctx.temp3, ctx.eps, ctx.dt = float(temp3), float(eps), (img.dtype, txt.dtype)
+        return sim
+
+    @staticmethod
+    def backward(ctx, dsim):
+        a, t, ni, nt = ctx.saved_tensors
+        Bi, D = a.shape
+        Bt = t.shape[0]
+        d = dsim.float().contiguous()
+        da, dt_ = torch.empty_like(a), torch.empty_like(t)
+        N.check(N.lib().glr_global_sim_bwd(N.ptr(a), N.ptr(t), N.ptr(ni), N.ptr(nt), N.ptr(d), Bt, Bi, Bt, D,
+                                           ctx.temp3, ctx.eps, N.ptr(da), N.ptr(dt_), N.stream()),
+                "glr_global_sim_bwd")
+        return da.to(ctx.dt[0]), dt_.to(ctx.dt[1]), None, None
+
+
+def global_similarity(cnn_code, rnn_code, eps=1e-8, temp3=10.0):
+    """temp3 * cosine matrix [B_img, B_txt] (ref :75-80)."""
+    return GlobalSimFn.apply(cnn_code, rnn_code, temp3, eps)
+
+
+# ------------------------------------------------------------------------------------------
+# the reference's public functions
+# ------------------------------------------------------------------------------------------
+
+def cosine_similarity(x1, x2, dim=1, eps=1e-8):
+    """Returns cosine similarity between x1 and x2, computed along dim (ref :11-16: the clamp is
+    applied to the product of the norms).  Thin elementwise helper kept for API parity; inside
+    local_loss the cosine is fused into the K1 epilogue."""
+    N.require_cuda(x1, x2)
+    w12 = torch.sum(x1 * x2, dim)
+    w1 = torch.norm(x1, 2, dim)
+    w2 = torch.norm(x2, 2, dim)
+    return (w12 / (w1 * w2).clamp(min=eps)).squeeze()
+
+
+def attention_fn(query, context, temp1, no_attn_vec=None):
+    """
+    query: batch x ndf x queryL
+    context: batch x ndf x ih x iw (sourceL=ihxiw)
+    returns (weightedContext [batch, ndf, queryL], attn [batch, queryL, ih, iw])   (ref :19-63)
+    One launch of K1 in pair mode: image b attends with query b.
+    """
+    B, D, n = query.shape
+    ih, iw = context.size(2), context.size(3)
+    plan = N.TilePlan([n] * B, query.device)
+    opts = _Opts(temp1, 1.0, 1.0, "sum", 1e-8, True, 0, 0, True, True)
+    _, attn, wctx = LocalSimFn.apply(context, query, no_attn_vec, plan, opts)
+    return wctx[:, :, :n].to(query.dtype), attn.view(B, n, ih, iw).to(query.dtype)
+
+
+def global_loss(cnn_code, rnn_code, eps=1e-8, temp3=10.0):
+    """(loss0, loss1) of the global image-sentence InfoNCE (ref :66-88)."""
+    if cnn_code.dim() == 3:
+        cnn_code, rnn_code = cnn_code.squeeze(0), rnn_code.squeeze(0)
+    sim = global_similarity(cnn_code, rnn_code, eps=eps, temp3=temp3)
+    return dual_cross_entropy(sim)
+
+
+def local_similarity(img_features, words_emb, cap_lens: Sequence[int], temp1=4.0, temp2=5.0, temp3=10.0,
+                     agg="sum", no_attn_vec=None, eps=1e-8, want_attn=True, img_offset=0, word_start=0):
+    """B_img x n_sent similarity matrix (already * temp3) + flat diagonal attention maps + plan."""
+    plan = N.TilePlan([int(c) for c in cap_lens], img_features.device)
+    opts = _Opts(temp1, temp2, temp3, agg, eps, want_attn, img_offset, word_start, False, False)
+    sim, attn, _ = LocalSimFn.apply(img_features, words_emb, no_attn_vec, plan, opts)
+    return sim, attn, plan
+
+
+def split_attention_maps(attn_flat, cap_lens, ih, iw, first=0, count=None) -> List[torch.Tensor]:
+    """flat diagonal maps -> the reference's list of [1, n_i, ih, iw] tensors (ref :141-143)."""
+    count = len(cap_lens) if count is None else count
+    maps, off = [], int(sum(int(c) for c in cap_lens[:first])) * ih * iw
+    for i in range(first, first + count):
+        n = int(cap_lens[i])
+        maps.append(attn_flat[off:off + n * ih * iw].view(1, n, ih, iw))
+        off += n * ih * iw
+    return maps
+
+
+def local_loss(
+    img_features, words_emb, cap_lens, temp1=4.0, temp2=5.0, temp3=10.0, agg="sum", no_attn_vec=None,
+    no_attn_loss_weight=None, attention_divergence_loss_weight=None, attention_entropy_loss_weight=None
+):
+    """Local region x word InfoNCE (ref :99-201).  Returns
+    (loss0, loss1, no_attn_loss, kl_loss, entropy_loss, att_maps)."""
+    if (no_attn_loss_weight is not None or attention_divergence_loss_weight is not None
+            or attention_entropy_loss_weight is not None):
+        raise NotImplementedError(
+            "attention regularisers (no_attn / divergence / entropy weights, ref :108-114,172-199) are not "
+            "built yet in the MI355X path (SURVEY.md 8f-1)")
+    ih, iw = img_features.shape[2], img_features.shape[3]
+    cap_lens = [int(c) for c in cap_lens]
+    sim, attn, _ = local_similarity(img_features, words_emb, cap_lens, temp1, temp2, temp3, agg, no_attn_vec)
+    loss0, loss1 = dual_cross_entropy(sim)
+    att_maps = split_attention_maps(attn, cap_lens, ih, iw)
+    return loss0, loss1, 0, 0, 0, att_maps

@@ -233,9 +233,13 @@ def local_similarity_matrix(img_features, words_emb, cap_lens: Sequence[int], te
         dot = (ctx * T.unsqueeze(0)).sum(-1)
         cos = dot / (ctx.norm(2, dim=-1) * tnorm.unsqueeze(0)).clamp(min=eps)
         ex = torch.exp(cos * temp2)                          # [c, N]
-        acc = torch.zeros(ex.shape[0], nsent, dtype=ex.dtype).scatter_add(1, seg.expand(ex.shape), ex)
-        if agg != "sum":
-            acc = acc / torch.tensor([float(n) for n in cap_lens], dtype=ex.dtype)
+        if agg == "max":                                     # inference variant, gloria_model.py:199
+            acc = torch.zeros(ex.shape[0], nsent, dtype=ex.dtype).scatter_reduce(
+                1, seg.expand(ex.shape), ex, "amax", include_self=False)
+        else:
+            acc = torch.zeros(ex.shape[0], nsent, dtype=ex.dtype).scatter_add(1, seg.expand(ex.shape), ex)
+            if agg != "sum":
+                acc = acc / torch.tensor([float(n) for n in cap_lens], dtype=ex.dtype)
         sims.append(torch.log(acc) * temp3)
         if return_attn:
             attns.append(a2.transpose(1, 2))                 # [c, N, S]
