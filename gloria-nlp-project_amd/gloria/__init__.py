@@ -2,3 +2,4 @@
 `gloria.builder` / `gloria.lightning.PretrainModel` / `gloria.loss.gloria_loss` surface)."""
 
 from . import loss  # noqa: F401
+from . import builder  # noqa: F401

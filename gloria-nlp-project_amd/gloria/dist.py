@@ -1,0 +1,115 @@
+"""Data-parallel plumbing: one process per GPU, torch.distributed (backend "nccl" = RCCL over xGMI;
+"gloo" in the CPU tests).  The reference has no collective call sites at all; this is
+new capability whose oracle is the single-process full-batch result.
+
+Collectives on the path:
+  * all-gather of text embeddings (word-level [B, D, L] and global [B, D]) with a reduce-scatter
+    of their gradients in backward;
+  * all-gather of the similarity block-rows (256 KB at B = 256) for the column cross entropy;
+  * bucketed SUM all-reduce of parameter gradients (flat buckets, launched as soon as a bucket's
+    gradients are ready would be the next step; round 1 launches all buckets asynchronously after
+    backward and waits once).  xGMI is point-to-point, so buckets are large (64 MiB) to amortise
+    per-collective latency and let RCCL use all 7 links.
+The loss every rank differentiates is the GLOBAL-batch mean, so gradients are summed, not averaged.
+"""
+
+import os
+
+import torch
+import torch.distributed as dist
+
+
+class _AllGatherGrad(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, group):
+        ctx.group = group
+        world = dist.get_world_size(group)
+        x = x.contiguous()
+        out = torch.empty((world * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+        dist.all_gather_into_tensor(out, x, group=group)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        group = ctx.group
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        g = g.contiguous()
+        n = g.shape[0] // world
+        if dist.get_backend(group) == "gloo":          # gloo has no reduce_scatter
+            dist.all_reduce(g, group=group)
+            return g[rank * n:(rank + 1) * n].clone(), None
+        out = torch.empty((n,) + tuple(g.shape[1:]), dtype=g.dtype, device=g.device)
+        dist.reduce_scatter_tensor(out, g, group=group)
+        return out, None
+
+
+class DistContext:
+    def __init__(self, group=None):
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.world_size = dist.get_world_size(group)
+
+    # -- embeddings
+    def all_gather_grad(self, x):
+        return _AllGatherGrad.apply(x, self.group)
+
+    def all_gather_nograd(self, x):
+        x = x.detach().contiguous()
+        out = torch.empty((self.world_size * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+        dist.all_gather_into_tensor(out, x, group=self.group)
+        return out
+
+    def all_gather_ints(self, values):
+        """host int lists of equal length per rank -> concatenated host list (one small collective)."""
+        dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(self.group) == "nccl" else "cpu"
+        t = torch.tensor(list(values), dtype=torch.int32, device=dev)
+        out = torch.empty(self.world_size * t.numel(), dtype=torch.int32, device=dev)
+        dist.all_gather_into_tensor(out, t, group=self.group)
+        return out.cpu().tolist()
+
+    # -- parameter gradients
+    def allreduce_grads(self, params, bucket_bytes=64 << 20):
+        """SUM all-reduce of .grad over the group in flat buckets; returns after all buckets landed."""
+        buckets, cur, size = [], [], 0
+        for p in params:
+            if p.grad is None:
+                continue
+            cur.append(p)
+            size += p.grad.numel() * p.grad.element_size()
+            if size >= bucket_bytes:
+                buckets.append(cur)
+                cur, size = [], 0
+        if cur:
+            buckets.append(cur)
+        pending = []
+        for b in buckets:
+            flat = torch.cat([p.grad.reshape(-1) for p in b])
+            work = dist.all_reduce(flat, group=self.group, async_op=True)
+            pending.append((work, flat, b))
+        for work, flat, b in pending:
+            work.wait()
+            off = 0
+            for p in b:
+                n = p.grad.numel()
+                p.grad.copy_(flat[off:off + n].view_as(p.grad))
+                off += n
+
+    def barrier(self):
+        dist.barrier(group=self.group)
+
+
+def init_from_env(backend=None):
+    """Initialise torch.distributed from RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torchrun)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world <= 1:
+        return None
+    if not dist.is_initialized():
+        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend=backend)
+    return DistContext()

@@ -24,6 +24,7 @@ from .. import _native as N
 from . import _recompute as R
 
 _COMPUTE_DTYPE = None          # None = follow the input dtype
+K1_EVENTS = None               # bench.py sets this to a list to collect (start, end, flops) of every K1 launch
 
 
 def set_compute_dtype(dtype: Optional[torch.dtype]):
@@ -97,12 +98,19 @@ def _launch_local(img3, words, no_attn_vec, plan, o):
     if o.want_wctx:
         ld_wctx = int(plan.cap_lens_host.max())
         wctx = torch.zeros(B, D, ld_wctx, dtype=torch.float32, device=dev)
+    if K1_EVENTS is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
     N.check(L.glr_local_attn_fwd(N.ptr(vt), N.ptr(vd), N.ptr(tp), N.ptr(tnorm), N.ptr(plan.sent_slot0),
                                  N.ptr(plan.cap_lens), N.ptr(plan.tile_first), N.ptr(plan.order),
                                  N.ptr(plan.tile_nsub), plan.n_tiles, n_sent, B, D, s_eff, o.temp1, o.temp2,
                                  o.temp3, N.AGG[o.agg], o.eps, N.ptr(sim), n_sent, N.ptr(attn), N.ptr(attn_off),
                                  shift, N.ptr(wctx), ld_wctx, 1 if o.pair_only else 0, o.img_offset, code, st),
             "glr_local_attn_fwd")
+    if K1_EVENTS is not None:
+        ev1.record()
+        n_words = plan.n_words if not o.pair_only else int(plan.cap_lens_host[o.img_offset:o.img_offset + B].sum() // max(B, 1))
+        K1_EVENTS.append((ev0, ev1, (4.0 * s_eff * D + 6.0 * D) * B * n_words))
     return sim, attn, wctx
 
 

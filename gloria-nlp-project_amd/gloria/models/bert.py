@@ -1,0 +1,164 @@
+"""BERT-base encoder on plain torch ops (hipBLASLt GEMMs + fused SDPA on ROCm), parameter names
+identical to HuggingFace `BertModel` so `gloria.text_encoder.model.*` keys of reference checkpoints
+load unchanged (the reference builds it with AutoModel.from_pretrained,
+/root/reference/gloria/models/text_model.py:18-20).  transformers is not needed at run time.
+"""
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+class BertConfig:
+    def __init__(self, vocab_size=28996, hidden_size=768, num_hidden_layers=12, num_attention_heads=12,
+                 intermediate_size=3072, max_position_embeddings=512, type_vocab_size=2,
+                 hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1, layer_norm_eps=1e-12):
+        self.vocab_size, self.hidden_size = vocab_size, hidden_size
+        self.num_hidden_layers, self.num_attention_heads = num_hidden_layers, num_attention_heads
+        self.intermediate_size, self.max_position_embeddings = intermediate_size, max_position_embeddings
+        self.type_vocab_size = type_vocab_size
+        self.hidden_dropout_prob, self.attention_probs_dropout_prob = hidden_dropout_prob, attention_probs_dropout_prob
+        self.layer_norm_eps = layer_norm_eps
+
+
+class BertEmbeddings(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.word_embeddings = nn.Embedding(c.vocab_size, c.hidden_size, padding_idx=0)
+        self.position_embeddings = nn.Embedding(c.max_position_embeddings, c.hidden_size)
+        self.token_type_embeddings = nn.Embedding(c.type_vocab_size, c.hidden_size)
+        self.LayerNorm = nn.LayerNorm(c.hidden_size, eps=c.layer_norm_eps)
+        self.dropout = nn.Dropout(c.hidden_dropout_prob)
+        self.register_buffer("position_ids", torch.arange(c.max_position_embeddings).unsqueeze(0), persistent=False)
+
+    def forward(self, ids, token_type):
+        L = ids.shape[1]
+        if token_type is None:
+            token_type = torch.zeros_like(ids)
+        x = self.word_embeddings(ids) + self.token_type_embeddings(token_type) + \
+            self.position_embeddings(self.position_ids[:, :L])
+        return self.dropout(self.LayerNorm(x))
+
+
+class BertSelfAttention(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.nh, self.hd = c.num_attention_heads, c.hidden_size // c.num_attention_heads
+        self.query = nn.Linear(c.hidden_size, c.hidden_size)
+        self.key = nn.Linear(c.hidden_size, c.hidden_size)
+        self.value = nn.Linear(c.hidden_size, c.hidden_size)
+        self.p = c.attention_probs_dropout_prob
+
+    def forward(self, x, bias):
+        B, L, H = x.shape
+        q = self.query(x).view(B, L, self.nh, self.hd).transpose(1, 2)
+        k = self.key(x).view(B, L, self.nh, self.hd).transpose(1, 2)
+        v = self.value(x).view(B, L, self.nh, self.hd).transpose(1, 2)
+        o = F.scaled_dot_product_attention(q, k, v, attn_mask=bias, dropout_p=self.p if self.training else 0.0)
+        return o.transpose(1, 2).reshape(B, L, H)
+
+
+class BertSelfOutput(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.dense = nn.Linear(c.hidden_size, c.hidden_size)
+        self.LayerNorm = nn.LayerNorm(c.hidden_size, eps=c.layer_norm_eps)
+        self.dropout = nn.Dropout(c.hidden_dropout_prob)
+
+    def forward(self, h, inp):
+        return self.LayerNorm(self.dropout(self.dense(h)) + inp)
+
+
+class BertAttention(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.self = BertSelfAttention(c)
+        self.output = BertSelfOutput(c)
+
+    def forward(self, x, bias):
+        return self.output(self.self(x, bias), x)
+
+
+class BertIntermediate(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.dense = nn.Linear(c.hidden_size, c.intermediate_size)
+
+    def forward(self, x):
+        return F.gelu(self.dense(x))
+
+
+class BertOutput(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.dense = nn.Linear(c.intermediate_size, c.hidden_size)
+        self.LayerNorm = nn.LayerNorm(c.hidden_size, eps=c.layer_norm_eps)
+        self.dropout = nn.Dropout(c.hidden_dropout_prob)
+
+    def forward(self, h, inp):
+        return self.LayerNorm(self.dropout(self.dense(h)) + inp)
+
+
+class BertLayer(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.attention = BertAttention(c)
+        self.intermediate = BertIntermediate(c)
+        self.output = BertOutput(c)
+
+    def forward(self, x, bias):
+        a = self.attention(x, bias)
+        return self.output(self.intermediate(a), a)
+
+
+class BertEncoderStack(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.layer = nn.ModuleList([BertLayer(c) for _ in range(c.num_hidden_layers)])
+
+
+class BertPooler(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.dense = nn.Linear(c.hidden_size, c.hidden_size)
+
+    def forward(self, x):
+        return torch.tanh(self.dense(x[:, 0]))
+
+
+class BertModel(nn.Module):
+    """forward(ids, attention_mask, token_type_ids) -> (last_hidden, pooled, all_hidden_states)
+    like HF BertModel(output_hidden_states=True) indexed positionally (outputs[0], [1], [2])."""
+
+    def __init__(self, config=None):
+        super().__init__()
+        self.config = c = config or BertConfig()
+        self.embeddings = BertEmbeddings(c)
+        self.encoder = BertEncoderStack(c)
+        self.pooler = BertPooler(c)
+        self.apply(self._init)
+
+    @staticmethod
+    def _init(m):
+        if isinstance(m, nn.Linear):
+            nn.init.normal_(m.weight, std=0.02)
+            nn.init.zeros_(m.bias)
+        elif isinstance(m, nn.Embedding):
+            nn.init.normal_(m.weight, std=0.02)
+            if m.padding_idx is not None:
+                with torch.no_grad():
+                    m.weight[m.padding_idx].zero_()
+        elif isinstance(m, nn.LayerNorm):
+            nn.init.ones_(m.weight)
+            nn.init.zeros_(m.bias)
+
+    def forward(self, ids, attention_mask=None, token_type_ids=None):
+        x = self.embeddings(ids, token_type_ids)
+        bias = None
+        if attention_mask is not None:          # boolean key mask (True = attend), broadcast over heads/queries
+            bias = (attention_mask != 0)[:, None, None, :]
+        hidden = [x]
+        for layer in self.encoder.layer:
+            x = layer(x, bias)
+            hidden.append(x)
+        return x, self.pooler(x), tuple(hidden)

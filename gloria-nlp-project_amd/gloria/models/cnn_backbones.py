@@ -1,0 +1,91 @@
+"""ResNet-50 backbone factory with the reference's contract
+(/root/reference/gloria/models/cnn_backbones.py:31-35): returns (model, feature_dim, interm_dim) with
+the classifier replaced by identity.  torchvision is not available here, so the bottleneck stack is
+defined directly on torch ops (MIOpen convolutions on ROCm); parameter names match torchvision's
+resnet50 so reference checkpoints (`gloria.img_encoder.model.layer3...`) load unchanged.
+"""
+
+import os
+import warnings
+
+import torch
+import torch.nn as nn
+
+
+class Identity(nn.Module):
+    def forward(self, x):
+        return x
+
+
+class Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, stride=stride, padding=1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
+        self.bn3 = nn.BatchNorm2d(planes * 4)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+
+    def forward(self, x):
+        identity = x
+        out = self.relu(self.bn1(self.conv1(x)))
+        out = self.relu(self.bn2(self.conv2(out)))
+        out = self.bn3(self.conv3(out))
+        if self.downsample is not None:
+            identity = self.downsample(x)
+        return self.relu(out + identity)
+
+
+class ResNet50(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.inplanes = 64
+        self.conv1 = nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(3, stride=2, padding=1)
+        self.layer1 = self._make_layer(64, 3, 1)
+        self.layer2 = self._make_layer(128, 4, 2)
+        self.layer3 = self._make_layer(256, 6, 2)
+        self.layer4 = self._make_layer(512, 3, 2)
+        self.avgpool = nn.AdaptiveAvgPool2d((1, 1))
+        self.fc = nn.Linear(2048, 1000)
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.ones_(m.weight)
+                nn.init.zeros_(m.bias)
+
+    def _make_layer(self, planes, blocks, stride):
+        downsample = None
+        if stride != 1 or self.inplanes != planes * 4:
+            downsample = nn.Sequential(nn.Conv2d(self.inplanes, planes * 4, 1, stride=stride, bias=False),
+                                       nn.BatchNorm2d(planes * 4))
+        layers = [Bottleneck(self.inplanes, planes, stride, downsample)]
+        self.inplanes = planes * 4
+        layers += [Bottleneck(self.inplanes, planes) for _ in range(1, blocks)]
+        return nn.Sequential(*layers)
+
+    def forward(self, x):
+        x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
+        x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
+        return self.fc(torch.flatten(self.avgpool(x), 1))
+
+
+def resnet_50(pretrained=True):
+    """(model, 2048, 1024).  `pretrained` may be a path to a torchvision resnet50 state_dict; with
+    True and no network access the weights are the Kaiming initialisation (a warning says so)."""
+    model = ResNet50()
+    if isinstance(pretrained, str) and os.path.exists(pretrained):
+        model.load_state_dict(torch.load(pretrained, map_location="cpu", weights_only=True))
+    elif pretrained:
+        warnings.warn("resnet_50(pretrained=True): no ImageNet weights available offline, using random init")
+    feature_dims = model.fc.in_features
+    model.fc = Identity()
+    return model, feature_dims, 1024

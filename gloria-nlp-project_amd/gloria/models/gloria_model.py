@@ -1,0 +1,176 @@
+"""GLoRIA nn.Module with the reference's interface
+(/root/reference/gloria/models/gloria_model.py:45-211): same constructor contract, attribute names
+(`text_encoder`, `img_encoder`, `no_attn_vec`, loss weights, temps), `forward`, `calc_loss`,
+`_calc_local_loss`, `_calc_global_loss`, `get_global_similarities`, `get_local_similarities`,
+`get_attn_maps`.  Host-side inference utilities of the reference (process_text / process_img /
+plotting, :213-384) are out of scope.
+
+Data-parallel extension: when `self.dist` is a gloria.dist.DistContext with world_size > 1, calc_loss
+forms the FULL global-batch contrastive matrices: text embeddings are all-gathered over RCCL, this
+rank computes its block-row of the similarity matrices with the HIP kernels, the block-rows are
+all-gathered for the column-direction cross entropy, and gradients of the gathered text embeddings
+are reduce-scattered back.  The reference's own 'dp' mode (per-replica negatives) is
+not reproduced.
+"""
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import builder
+from .. import loss
+from ..loss import gloria_loss as GL
+
+
+class PositionEmbeddings(nn.Module):
+    """Ref gloria_model.py:17-42 (optional, off in the pretrain configs)."""
+
+    def __init__(self, num_positions, hidden_size, num_spatial_dims=1):
+        super().__init__()
+        self.num_positions, self.hidden_size, self.num_spatial_dims = num_positions, hidden_size, num_spatial_dims
+        self.image_position_embeddings = nn.Embedding(num_positions, hidden_size // num_spatial_dims)
+
+    def forward(self, spatial_shape):
+        if isinstance(spatial_shape, int):
+            spatial_shape = (spatial_shape,) * self.num_spatial_dims
+        for d in spatial_shape:
+            assert d <= self.num_positions
+        device = self.image_position_embeddings.weight.device
+        embs = [self.image_position_embeddings(torch.arange(d, device=device)) for d in spatial_shape]
+        pos_dim = embs[0].shape[-1]
+        embs = [e.reshape(*(1 if i != j else d for j, d in enumerate(spatial_shape)), pos_dim)
+                 .expand(*spatial_shape, pos_dim) for i, e in enumerate(embs)]
+        pad = torch.zeros(*spatial_shape, self.hidden_size - len(spatial_shape) * pos_dim, device=device)
+        return torch.cat(embs + [pad], -1)
+
+
+class GLoRIA(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.cfg = cfg
+        self.text_encoder = builder.build_text_model(cfg)
+        self.img_encoder = builder.build_img_model(cfg)
+        self.position_embeddings = PositionEmbeddings(
+            cfg.model.image_position_embeddings.num, cfg.model.text.embedding_dim, num_spatial_dims=2) \
+            if cfg.model.image_position_embeddings is not None else None
+        self.image_transformer = nn.TransformerEncoder(
+            nn.TransformerEncoderLayer(cfg.model.text.embedding_dim, cfg.model.image_transformer.num_heads),
+            cfg.model.image_transformer.num_layers) if "image_transformer" in cfg.model.keys() else None
+        self.no_attn_vec = nn.Parameter(torch.randn(cfg.model.text.embedding_dim)) \
+            if cfg.model.gloria.no_attn_vec else None
+
+        self.local_loss = loss.gloria_loss.local_loss
+        self.global_loss = loss.gloria_loss.global_loss
+        g = cfg.model.gloria
+        self.local_loss_weight = g.local_loss_weight
+        self.global_loss_weight = g.global_loss_weight
+        self.sparse_attn_loss_weight = g.sparse_attn_loss_weight
+        self.no_attn_loss_weight = g.no_attn_loss_weight
+        self.attention_divergence_loss_weight = g.attention_divergence_loss_weight
+        self.attention_entropy_loss_weight = g.attention_entropy_loss_weight
+        self.segmentation_loss_weight = g.segmentation_loss_weight
+        self.temp1, self.temp2, self.temp3 = g.temp1, g.temp2, g.temp3
+        self.batch_size = cfg.train.batch_size
+        self.dist = None                        # set by the trainer for data-parallel runs
+        self.ixtoword = None                    # reference attribute (:79); strings live in text_encoder.vocab
+
+    # ------------------------------------------------------------------ encoders (ref :81-103)
+    def text_encoder_forward(self, caption_ids, attention_mask, token_type_ids):
+        return self.text_encoder(caption_ids, attention_mask, token_type_ids)
+
+    def image_encoder_forward(self, imgs):
+        img_feat_g, img_emb_l = self.img_encoder(imgs, get_local=True)
+        img_emb_g, img_emb_l = self.img_encoder.generate_embeddings(img_feat_g, img_emb_l)
+        b, c, h, w = img_emb_l.shape
+        if self.position_embeddings is not None:
+            pos = self.position_embeddings((h, w)).permute(2, 0, 1).expand(b, c, h, w)
+            img_emb_l = img_emb_l + pos
+        if self.image_transformer is not None:
+            flat = img_emb_l.reshape(b, c, h * w).permute(2, 0, 1)
+            img_emb_l = self.image_transformer(flat).permute(1, 2, 0).reshape(b, c, h, w)
+        return img_emb_l, img_emb_g
+
+    # ------------------------------------------------------------------ losses (ref :105-150)
+    @staticmethod
+    def _cap_lens(sents):
+        if hasattr(sents, "cap_lens"):                # SentenceBatch: same rule, computed without strings
+            return list(sents.cap_lens)
+        return [len([w for w in sent if not w.startswith("[")]) + 1 for sent in sents]
+
+    def _calc_local_loss(self, img_emb_l, text_emb_l, sents):
+        cap_lens = self._cap_lens(sents)
+        if self.dist is not None and self.dist.world_size > 1:
+            return self._calc_local_loss_sharded(img_emb_l, text_emb_l, cap_lens)
+        return self.local_loss(
+            img_emb_l, text_emb_l, cap_lens, temp1=self.temp1, temp2=self.temp2, temp3=self.temp3,
+            no_attn_vec=self.no_attn_vec, no_attn_loss_weight=self.no_attn_loss_weight,
+            attention_divergence_loss_weight=self.attention_divergence_loss_weight,
+            attention_entropy_loss_weight=self.attention_entropy_loss_weight)
+
+    def _calc_local_loss_sharded(self, img_emb_l, text_emb_l, cap_lens):
+        if (self.no_attn_loss_weight is not None or self.attention_divergence_loss_weight is not None
+                or self.attention_entropy_loss_weight is not None):
+            raise NotImplementedError("attention regularisers are not built yet (SURVEY.md 8f-1)")
+        d = self.dist
+        b_loc = img_emb_l.shape[0]
+        words_all = d.all_gather_grad(text_emb_l)                       # [B, D, L], grads reduce-scattered
+        lens_all = d.all_gather_ints(cap_lens)
+        sim_rows, attn, _ = GL.local_similarity(img_emb_l, words_all, lens_all, self.temp1, self.temp2,
+                                                self.temp3, "sum", self.no_attn_vec, img_offset=d.rank * b_loc)
+        sim_full = d.all_gather_nograd(sim_rows)
+        l0, l1 = GL.dual_cross_entropy(sim_rows, sim_full, d.rank * b_loc)
+        ih, iw = img_emb_l.shape[2], img_emb_l.shape[3]
+        maps = GL.split_attention_maps(attn, lens_all, ih, iw, first=d.rank * b_loc, count=b_loc)
+        return l0, l1, 0, 0, 0, maps
+
+    def _calc_global_loss(self, img_emb_g, text_emb_g):
+        if self.dist is not None and self.dist.world_size > 1:
+            d = self.dist
+            txt_all = d.all_gather_grad(text_emb_g)
+            sim_rows = GL.global_similarity(img_emb_g, txt_all, temp3=self.temp3)
+            sim_full = d.all_gather_nograd(sim_rows)
+            return GL.dual_cross_entropy(sim_rows, sim_full, d.rank * img_emb_g.shape[0])
+        return self.global_loss(img_emb_g, text_emb_g, temp3=self.temp3)
+
+    def calc_loss(self, img_emb_l, img_emb_g, text_emb_l, text_emb_g, sents, segmentation_labels=None):
+        loss_ = 0
+        l_loss0, l_loss1, no_attn_loss, kl_loss, entropy_loss, attn_maps = self._calc_local_loss(
+            img_emb_l, text_emb_l, sents)
+        if self.local_loss_weight != 0:
+            loss_ = loss_ + (l_loss0 + l_loss1) * self.local_loss_weight
+        if self.global_loss_weight != 0:
+            g_loss0, g_loss1 = self._calc_global_loss(img_emb_g, text_emb_g)
+            loss_ = loss_ + (g_loss0 + g_loss1) * self.global_loss_weight
+        if segmentation_labels is not None and self.segmentation_loss_weight:
+            # attention-supervision term (ref :143-147)
+            mean_maps = torch.cat([m.mean(1) for m in attn_maps], 0)
+            up = nn.functional.interpolate(mean_maps.unsqueeze(1), size=segmentation_labels.shape[1:]).squeeze(1)
+            up = up / up.sum(-1, keepdim=True).sum(-2, keepdim=True)
+            seg = -torch.log((segmentation_labels * up).sum(-1).sum(-1)).mean()
+            if self.dist is not None and self.dist.world_size > 1:
+                seg = seg / self.dist.world_size          # mean over the global batch
+            loss_ = loss_ + seg * self.segmentation_loss_weight
+        loss_ = loss_ + no_attn_loss + kl_loss + entropy_loss
+        return loss_, attn_maps
+
+    def forward(self, x):
+        img_emb_l, img_emb_g = self.image_encoder_forward(x["imgs"])
+        text_emb_l, text_emb_g, sents = self.text_encoder_forward(
+            x["caption_ids"], x["attention_mask"], x["token_type_ids"])
+        return img_emb_l, img_emb_g, text_emb_l, text_emb_g, sents
+
+    # ------------------------------------------------------------------ inference helpers (ref :164-211)
+    def get_global_similarities(self, img_emb_g, text_emb_g):
+        with torch.no_grad():
+            return GL.global_similarity(img_emb_g, text_emb_g, temp3=1.0).detach().cpu()
+
+    def get_local_similarities(self, img_emb_l, text_emb_l, cap_lens):
+        """words 1..n (skips [CLS]), temps 4/5, MAX over words, no temp3 (ref :171-207)."""
+        with torch.no_grad():
+            sim, _, _ = GL.local_similarity(img_emb_l, text_emb_l, [int(c) for c in cap_lens], 4.0, 5.0, 1.0,
+                                            "max", self.no_attn_vec, want_attn=False, word_start=1)
+        return sim.detach().cpu()
+
+    def get_attn_maps(self, img_emb_l, text_emb_l, sents):
+        _, _, _, _, _, attn_maps = self._calc_local_loss(img_emb_l, text_emb_l, sents)
+        return attn_maps

@@ -1,0 +1,56 @@
+"""ImageEncoder with the reference's interface (/root/reference/gloria/models/vision_model.py:8-86):
+bilinear upsample to 299x299 (align_corners=True, :70), ResNet-50 stem..layer3 -> local features
+[B, 1024, 19, 19] (:72-80), layer4 + avgpool -> global [B, 2048] (:81-84), then
+Linear(2048, 768) / bias-free Conv1x1(1024, 768) embedders (:20-28, :52-65).
+Parameter names equal the reference's (`model.*`, `global_embedder.*`, `local_embedder.weight`).
+"""
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import cnn_backbones
+
+
+class ImageEncoder(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.cfg = cfg
+        self.output_dim = cfg.model.text.embedding_dim
+        self.norm = cfg.model.norm
+        model_function = getattr(cnn_backbones, cfg.model.vision.model_name)
+        self.model, self.feature_dim, self.interm_feature_dim = model_function(
+            pretrained=cfg.model.vision.pretrained)
+        self.global_embedder = nn.Linear(self.feature_dim, self.output_dim)
+        self.local_embedder = nn.Conv2d(self.interm_feature_dim, self.output_dim, kernel_size=1, stride=1,
+                                        padding=0, bias=False)
+        self.pool = nn.AdaptiveAvgPool2d(output_size=(1, 1))
+        if cfg.model.vision.freeze_cnn:
+            print("Freezing CNN model")
+            for param in self.model.parameters():
+                param.requires_grad = False
+
+    def forward(self, x, get_local=False):
+        # --> fixed-size input: batch x 3 x 299 x 299
+        global_ft, local_ft = self.resnet_forward(x, extract_features=True)
+        return (global_ft, local_ft) if get_local else global_ft
+
+    def generate_embeddings(self, global_features, local_features):
+        global_emb = self.global_embedder(global_features)
+        local_emb = self.local_embedder(local_features)
+        if self.norm is True:
+            local_emb = local_emb / torch.norm(local_emb, 2, dim=1, keepdim=True).expand_as(local_emb)
+            global_emb = global_emb / torch.norm(global_emb, 2, dim=1, keepdim=True).expand_as(global_emb)
+        return global_emb, local_emb
+
+    def resnet_forward(self, x, extract_features=False):
+        x = F.interpolate(x, size=(299, 299), mode="bilinear", align_corners=True)
+        m = self.model
+        x = m.maxpool(m.relu(m.bn1(m.conv1(x))))       # (B, 64, 75, 75)
+        x = m.layer1(x)                                  # (B, 256, 75, 75)
+        x = m.layer2(x)                                  # (B, 512, 38, 38)
+        x = m.layer3(x)                                  # (B, 1024, 19, 19)
+        local_features = x
+        x = m.layer4(x)                                  # (B, 2048, 10, 10)
+        x = self.pool(x)
+        return x.view(x.size(0), -1), local_features

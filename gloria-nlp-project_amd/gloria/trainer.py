@@ -1,0 +1,132 @@
+"""Minimal training driver standing in for the Lightning Trainer the reference configures in
+run.py:172-207 (precision 16 -> bf16 autocast here, gradient_clip_val 0.25, Adam(0.5, 0.999),
+ReduceLROnPlateau, ModelCheckpoint-style save/resume with the reference's checkpoint layout).
+One process per GPU; with a DistContext the loss is the global-batch loss and parameter gradients
+are SUM-all-reduced before clipping (so the clip uses the global norm)."""
+
+import json
+import os
+import time
+
+import torch
+
+
+class Trainer:
+    def __init__(self, cfg, device="cuda", precision=None, dist_ctx=None, log_path=None):
+        self.cfg = cfg
+        self.device = torch.device(device)
+        prec = precision if precision is not None else cfg.lightning.trainer.precision
+        self.autocast_dtype = torch.bfloat16 if str(prec) in ("16", "bf16") else None
+        self.clip = cfg.lightning.trainer.gradient_clip_val
+        self.max_epochs = cfg.lightning.trainer.max_epochs or 1
+        self.dist = dist_ctx
+        self.log_path = log_path
+        self.global_step = 0
+        self.optimizer = self.scheduler = None
+
+    # ------------------------------------------------------------------ setup
+    def setup(self, model):
+        model.to(self.device)
+        if self.device.type == "cuda":
+            model.gloria.img_encoder.to(memory_format=torch.channels_last)
+        model.gloria.dist = self.dist
+        opt = model.configure_optimizers()
+        self.optimizer, self.scheduler = opt["optimizer"], opt["lr_scheduler"]
+        self.params = [p for g in self.optimizer.param_groups for p in g["params"]]
+        return model
+
+    def to_device(self, batch):
+        out = {}
+        for k, v in batch.items():
+            if torch.is_tensor(v):
+                v = v.to(self.device, non_blocking=True)
+                if k == "imgs" and self.device.type == "cuda":
+                    v = v.contiguous(memory_format=torch.channels_last)
+            out[k] = v
+        return out
+
+    # ------------------------------------------------------------------ one optimisation step
+    def training_step(self, model, batch, batch_idx=0):
+        batch = self.to_device(batch)
+        ctx = torch.autocast(self.device.type, dtype=self.autocast_dtype) if self.autocast_dtype else _Null()
+        with ctx:
+            out = model.training_step(batch, batch_idx)
+        loss = out["loss"]
+        self.optimizer.zero_grad(set_to_none=True)
+        loss.backward()
+        if self.dist is not None and self.dist.world_size > 1:
+            self.dist.allreduce_grads(self.params)
+        if self.clip:
+            torch.nn.utils.clip_grad_norm_(self.params, self.clip)
+        self.optimizer.step()
+        self.global_step += 1
+        return loss.detach()
+
+    @torch.no_grad()
+    def evaluate(self, model, loader, split="val"):
+        model.eval()
+        tot, n = 0.0, 0
+        for i, batch in enumerate(loader):
+            batch = self.to_device(batch)
+            ctx = torch.autocast(self.device.type, dtype=self.autocast_dtype) if self.autocast_dtype else _Null()
+            with ctx:
+                out = (model.validation_step if split == "val" else model.test_step)(batch, i)
+            tot += float(out["loss"])
+            n += 1
+        model.train()
+        return tot / max(n, 1)
+
+    # ------------------------------------------------------------------ fit loop
+    def fit(self, model, dm, max_steps=None, ckpt_dir=None):
+        self.setup(model)
+        model.train()
+        history = []
+        for epoch in range(self.max_epochs):
+            model.current_epoch = epoch
+            t0 = time.time()
+            for i, batch in enumerate(dm.train_dataloader()):
+                loss = self.training_step(model, batch, i)
+                history.append(float(loss))
+                self._log({"step": self.global_step, "epoch": epoch, "train_loss": history[-1]})
+                if max_steps is not None and self.global_step >= max_steps:
+                    break
+            val = self.evaluate(model, dm.val_dataloader())
+            self._log({"epoch": epoch, "val_loss": val, "epoch_s": time.time() - t0})
+            sch = self.scheduler["scheduler"] if self.scheduler else None
+            if sch is not None:
+                sch.step(val) if isinstance(sch, torch.optim.lr_scheduler.ReduceLROnPlateau) else sch.step()
+            if ckpt_dir and (self.dist is None or self.dist.rank == 0):
+                self.save_checkpoint(model, os.path.join(ckpt_dir, "last.ckpt"))
+            if max_steps is not None and self.global_step >= max_steps:
+                break
+        return history
+
+    def _log(self, rec):
+        if self.log_path and (self.dist is None or self.dist.rank == 0):
+            with open(self.log_path, "a") as f:
+                f.write(json.dumps(rec) + "\n")
+
+    # ------------------------------------------------------------------ checkpoints (reference layout + resume state)
+    def save_checkpoint(self, model, path):
+        os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
+        ckpt = model.checkpoint()
+        ckpt["optimizer_states"] = [self.optimizer.state_dict()]
+        ckpt["global_step"] = self.global_step
+        ckpt["epoch"] = model.current_epoch
+        torch.save(ckpt, path)
+
+    def resume(self, model, path):
+        ckpt = torch.load(path, map_location="cpu", weights_only=True)
+        model.load_state_dict(ckpt["state_dict"])
+        if self.optimizer is not None and "optimizer_states" in ckpt:
+            self.optimizer.load_state_dict(ckpt["optimizer_states"][0])
+        self.global_step = ckpt.get("global_step", 0)
+        model.current_epoch = ckpt.get("epoch", 0)
+
+
+class _Null:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False

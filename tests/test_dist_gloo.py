@@ -1,0 +1,139 @@
+"""world_size-2 tests of the data-parallel wiring on CPU (gloo): the sharded loss path of
+GLoRIA.calc_loss (text all-gather -> block-row similarity -> row all-gather -> dual CE, gradients
+reduce-scattered back) must reproduce the single-process full-batch result.  The HIP similarity
+functions are replaced by the CPU oracle here (tests may use the oracle; the product never does), so
+what is under test is the collective plumbing, offsets and gradient flow - not the kernels."""
+
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import golden_inputs as gi
+
+WORLD = 2
+B, D, H, W, L = 4, 64, 3, 3, 9
+CAP = [7, 5, 3, 2]
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _inputs():
+    img = torch.from_numpy(gi.normal(11, B, D, H, W))
+    words = torch.from_numpy(gi.normal(12, B, D, L))
+    ig = torch.from_numpy(gi.normal(13, B, D))
+    tg = torch.from_numpy(gi.normal(14, B, D))
+    return img, words, ig, tg
+
+
+def _patch_with_oracle():
+    """CPU stand-ins with the product functions' signatures, built on the oracle."""
+    from gloria.loss import gloria_loss as GL
+    from oracle import gloria_oracle as orc
+
+    def local_similarity(img, words, cap_lens, temp1=4.0, temp2=5.0, temp3=10.0, agg="sum", no_attn_vec=None,
+                         eps=1e-8, want_attn=True, img_offset=0, word_start=0):
+        sim, a2, seg = orc.local_similarity_matrix(img, words, cap_lens, temp1, temp2, temp3, agg, no_attn_vec,
+                                                   return_attn=True)
+        woff = np.concatenate([[0], np.cumsum(cap_lens)])
+        S = img.shape[2] * img.shape[3]
+        flat = torch.zeros(int(woff[-1]) * S)
+        parts = []
+        for b in range(img.shape[0]):
+            i = img_offset + b
+            parts.append((int(woff[i]) * S, a2[b, woff[i]:woff[i + 1]].reshape(-1)))
+        for off, p in parts:
+            flat = torch.cat([flat[:off], p, flat[off + p.numel():]])
+        return sim, flat, None
+
+    def dual_cross_entropy(sim_rows, sim_full=None, row0=0):
+        if sim_full is None:
+            return orc.dual_ce(sim_rows)
+        full = torch.cat([sim_full[:row0], sim_rows, sim_full[row0 + sim_rows.shape[0]:]], 0)
+        return orc.dual_ce(full)
+
+    GL.local_similarity = local_similarity
+    GL.dual_cross_entropy = dual_cross_entropy
+    GL.global_similarity = lambda a, t, eps=1e-8, temp3=10.0: orc.global_similarity_matrix(a, t, eps, temp3)
+
+
+def _bare_gloria(dctx):
+    from gloria.models.gloria_model import GLoRIA
+    g = GLoRIA.__new__(GLoRIA)
+    torch.nn.Module.__init__(g)
+    g.dist = dctx
+    g.temp1, g.temp2, g.temp3 = 4.0, 5.0, 10.0
+    g.no_attn_vec = None
+    g.local_loss_weight = g.global_loss_weight = 1.0
+    g.no_attn_loss_weight = g.attention_divergence_loss_weight = g.attention_entropy_loss_weight = None
+    g.segmentation_loss_weight = None
+    return g
+
+
+def _worker(rank, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(WORLD))
+    dist.init_process_group("gloo", rank=rank, world_size=WORLD)
+    try:
+        from gloria.dist import DistContext
+        dctx = DistContext()
+        _patch_with_oracle()
+        img, words, ig, tg = _inputs()
+        per = B // WORLD
+        sl = slice(rank * per, (rank + 1) * per)
+        li, lw = img[sl].clone().requires_grad_(True), words[sl].clone().requires_grad_(True)
+        lig, ltg = ig[sl].clone().requires_grad_(True), tg[sl].clone().requires_grad_(True)
+
+        class Sents(list):
+            cap_lens = CAP[sl]
+        g = _bare_gloria(dctx)
+        loss, maps = g.calc_loss(li, lig, lw, ltg, Sents())
+        loss.backward()
+        # bucketed gradient all-reduce: sum over ranks
+        p = [torch.nn.Parameter(torch.zeros(5)), torch.nn.Parameter(torch.zeros(3, 2))]
+        p[0].grad = torch.full((5,), float(rank + 1))
+        p[1].grad = torch.full((3, 2), 10.0 * (rank + 1))
+        dctx.allreduce_grads(p, bucket_bytes=16)
+        ints = dctx.all_gather_ints([rank, rank + 10])
+        torch.save({"loss": loss.detach(), "gi": li.grad, "gw": lw.grad, "gig": lig.grad, "gtg": ltg.grad,
+                    "maps": [m.detach() for m in maps], "p0": p[0].grad, "p1": p[1].grad, "ints": ints},
+                   os.path.join(out, f"r{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_sharded_loss_equals_full_batch(tmp_path):
+    from oracle import gloria_oracle as orc
+    port = _free_port()
+    mp.spawn(_worker, args=(port, str(tmp_path)), nprocs=WORLD, join=True)
+    res = [torch.load(tmp_path / f"r{r}.pt", weights_only=False) for r in range(WORLD)]
+
+    img, words, ig, tg = _inputs()
+    fi, fw = img.clone().requires_grad_(True), words.clone().requires_grad_(True)
+    fig, ftg = ig.clone().requires_grad_(True), tg.clone().requires_grad_(True)
+    l = orc.local_loss(fi, fw, CAP)
+    gl_ = orc.global_loss(fig, ftg)
+    full = l[0] + l[1] + gl_[0] + gl_[1]
+    full.backward()
+    per = B // WORLD
+    for r in range(WORLD):
+        sl = slice(r * per, (r + 1) * per)
+        np.testing.assert_allclose(float(res[r]["loss"]), float(full), rtol=1e-5)
+        np.testing.assert_allclose(res[r]["gi"].numpy(), fi.grad[sl].numpy(), rtol=1e-4, atol=2e-6)
+        np.testing.assert_allclose(res[r]["gw"].numpy(), fw.grad[sl].numpy(), rtol=1e-4, atol=2e-6)
+        np.testing.assert_allclose(res[r]["gig"].numpy(), fig.grad[sl].numpy(), rtol=1e-4, atol=2e-6)
+        np.testing.assert_allclose(res[r]["gtg"].numpy(), ftg.grad[sl].numpy(), rtol=1e-4, atol=2e-6)
+        for k in range(per):
+            np.testing.assert_allclose(res[r]["maps"][k].numpy(), l[5][r * per + k].detach().numpy(), rtol=1e-5, atol=1e-7)
+        assert torch.equal(res[r]["p0"], torch.full((5,), 3.0)) and torch.equal(res[r]["p1"], torch.full((3, 2), 30.0))
+        assert res[r]["ints"] == [0, 10, 1, 11]

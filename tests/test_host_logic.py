@@ -1,0 +1,108 @@
+"""CPU tests of the host-side mirror: config semantics, word-piece slotting (against the reference's
+outputs in tests/golden/text.npz), builder/optimizer wiring, checkpoint key layout."""
+
+import numpy as np
+import pytest
+import torch
+
+import golden_inputs as gi
+
+
+def tiny_cfg(batch_size=4, **kw):
+    from gloria.config import pretrain_config
+    cfg = pretrain_config("imagenome", batch_size=batch_size, **kw)
+    cfg.set_path("model.text.bert_config", dict(vocab_size=2000, hidden_size=768, num_hidden_layers=1,
+                                                num_attention_heads=12, intermediate_size=256))
+    return cfg
+
+
+def test_config_missing_keys_read_as_none():
+    from gloria.config import Config
+    cfg = Config({"model": {"gloria": {"temp1": 4.0}}})
+    assert cfg.model.gloria.temp1 == 4.0
+    assert cfg.model.norm is None and cfg.model.gloria.no_attn_loss_weight is None
+    assert "image_transformer" not in cfg.model.keys()
+    cfg.set_path("train.scheduler.interval", "step")
+    assert cfg.train.scheduler.interval == "step"
+
+
+def test_reference_yaml_loads(tmp_path):
+    from gloria.config import load_config
+    p = tmp_path / "c.yaml"
+    p.write_text("phase: 'pretrain'\nmodel:\n  gloria:\n    temp1: 4.0\n    no_attn_vec: false\ntrain:\n  batch_size: 48\n")
+    cfg = load_config(str(p), {"train.batch_size": 8})
+    assert cfg.phase == "pretrain" and cfg.train.batch_size == 8 and cfg.model.gloria.no_attn_vec is False
+
+
+def test_wordpiece_slots_match_reference_outputs(golden):
+    """aggregate_tokens restated as host slotting + segment-sum == reference BertEncoder.forward"""
+    from gloria.models import text_model as tm
+    g = golden("text")
+    ids, hidden, vocab = gi.text_inputs()
+    enc = tm.BertEncoder.__new__(tm.BertEncoder)
+    torch.nn.Module.__init__(enc)
+    enc.vocab = tm.Vocab.from_dict(vocab)
+    summed = torch.stack([torch.from_numpy(h) for h in hidden[-4:]]).sum(0)
+    words, sents = enc.aggregate_tokens(summed, torch.from_numpy(ids))
+    np.testing.assert_allclose(words.permute(0, 2, 1).numpy(), g["text/word_emb"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(words.mean(1).numpy(), g["text/sent_emb"], rtol=1e-5, atol=1e-5)
+    assert ["\t".join(s) for s in sents] == list(g["text/sents"])
+    want = [sum(1 for w in s.split("\t") if not w.startswith("[")) + 1 for s in g["text/sents"]]
+    assert sents.cap_lens == want
+
+
+def test_wordpiece_without_sep_drops_last_word():
+    from gloria.models import text_model as tm
+    v = tm.Vocab(["[PAD]", "[CLS]", "[SEP]", "a", "##b", "c"])
+    ids = np.array([[1, 3, 4, 5, 5, 4]])            # no [SEP]: last open word ("c##b") is never flushed
+    dst, starts, n = tm.wordpiece_slots(ids, v)
+    assert n.tolist() == [3] and dst.tolist() == [[0, 1, 1, 2, -1, -1]]
+
+
+def test_builder_and_checkpoint_keys(tmp_path):
+    from gloria import builder
+    cfg = tiny_cfg()
+    dm = builder.build_data_module(cfg)
+    model = builder.build_lightning_model(cfg, dm)
+    keys = list(model.state_dict())
+    assert "gloria.img_encoder.local_embedder.weight" in keys
+    assert "gloria.img_encoder.global_embedder.bias" in keys
+    assert any(k.startswith("gloria.img_encoder.model.layer3.5.conv3") for k in keys)
+    assert "gloria.text_encoder.model.embeddings.word_embeddings.weight" in keys
+    assert "gloria.text_encoder.model.encoder.layer.0.attention.self.query.weight" in keys
+    opt = model.configure_optimizers()
+    assert opt["optimizer"].defaults["betas"] == (0.5, 0.999)
+    assert opt["lr_scheduler"]["monitor"] == "val_loss"
+    path = tmp_path / "last.ckpt"
+    torch.save(model.checkpoint(), path)
+    again = builder.build_lightning_model(cfg, dm, ckpt=str(path))
+    for (k1, v1), (k2, v2) in zip(model.state_dict().items(), again.state_dict().items()):
+        assert k1 == k2 and torch.equal(v1, v2)
+
+
+def test_no_attn_vec_parameter_name():
+    from gloria import builder
+    cfg = tiny_cfg(**{"model.gloria.no_attn_vec": True})
+    g = builder.build_gloria_model(cfg)
+    assert "no_attn_vec" in dict(g.named_parameters())
+
+
+def test_synthetic_batch_contract():
+    from gloria.datasets.synthetic import make_batch
+    b = make_batch(6, segmentation=True)
+    assert b["imgs"].shape == (6, 3, 224, 224) and b["imgs"].dtype == torch.float32
+    assert float(b["imgs"].min()) >= -1 and float(b["imgs"].max()) <= 1
+    assert b["caption_ids"].shape == (6, 97) and b["caption_ids"].dtype == torch.int64
+    lens = b["cap_lens"].tolist()
+    assert lens == sorted(lens, reverse=True)
+    assert (b["caption_ids"][:, 0] == 101).all()
+    frac = b["segmentation_labels"].float().mean((1, 2))
+    assert (frac > 0.03).all() and (frac < 0.5).all()
+
+
+def test_loss_refuses_cpu_and_unbuilt_features():
+    from gloria.loss import gloria_loss as GL
+    with pytest.raises(RuntimeError):
+        GL.global_loss(torch.zeros(2, 64), torch.zeros(2, 64))
+    with pytest.raises(NotImplementedError):
+        GL.local_loss(torch.zeros(2, 64, 3, 3), torch.zeros(2, 64, 5), [2, 2], no_attn_loss_weight=1.0)
