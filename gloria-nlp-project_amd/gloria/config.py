@@ -86,7 +86,7 @@ def pretrain_config(name="imagenome", batch_size=48, **overrides):
                      "aggregate_method": "sum", "norm": False, "embedding_dim": 768, "freeze_bert": False,
                      "agg_tokens": True},
         },
-        "data": {"dataset": name, "text": {"word_num": 97, "captions_per_image": 5,
+        "data": {"dataset": "chexpert" if name == "chexpert" else "imagenome", "text": {"word_num": 97, "captions_per_image": 5,
                                             "full_report": name != "chexpert"},
                  "image": {"imsize": 256}},
         "transforms": {"norm": "half", "random_crop": {"crop_size": 224}},
