@@ -13,37 +13,38 @@
 
 extern "C" int glr_version(void) { return 1; }
 
-extern "C" int glr_plan_tiles_bound(const int32_t* cap_lens, int n_sent) {
-  if (!cap_lens || n_sent <= 0) return GLR_EINVAL;
+extern "C" int glr_plan_tiles_bound(const int32_t* cap_lens, int n_sent, int capacity) {
+  if (!cap_lens || n_sent <= 0 || (capacity != 32 && capacity != GLR_TILE_WORDS)) return GLR_EINVAL;
   int total = 0;
   for (int i = 0; i < n_sent; ++i) {
     if (cap_lens[i] < 1 || cap_lens[i] > GLR_MAX_WORDS) return GLR_EINVAL;
-    total += (cap_lens[i] + GLR_TILE_WORDS - 1) / GLR_TILE_WORDS;
+    total += (cap_lens[i] + capacity - 1) / capacity;
   }
   return total;     // >= number of tiles and >= number of `order` entries
 }
 
-extern "C" int glr_plan_tiles(const int32_t* cap_lens, int n_sent, int32_t* sent_slot0, int32_t* tile_first,
-                              int32_t* order, int32_t* tile_nsub) {
+extern "C" int glr_plan_tiles(const int32_t* cap_lens, int n_sent, int capacity, int32_t* sent_slot0,
+                              int32_t* tile_first, int32_t* order, int32_t* tile_nsub) {
   if (!cap_lens || !sent_slot0 || !tile_first || !order || !tile_nsub || n_sent <= 0) return GLR_EINVAL;
-  std::vector<int> fill;                       // used slots per tile (GLR_TILE_WORDS = closed)
+  if (capacity != 32 && capacity != GLR_TILE_WORDS) return GLR_EINVAL;
+  std::vector<int> fill;                       // used slots per tile (capacity = closed)
   std::vector<std::vector<int>> members;
   std::vector<int> nsub;
   for (int i = 0; i < n_sent; ++i) {
     const int n = cap_lens[i];
     if (n < 1 || n > GLR_MAX_WORDS) return GLR_EINVAL;
-    if (n > GLR_TILE_WORDS) {                  // multi-tile sentence: its own run of consecutive tiles
-      const int k = (n + GLR_TILE_WORDS - 1) / GLR_TILE_WORDS;
+    if (n > capacity) {                        // multi-tile sentence: its own run of consecutive tiles
+      const int k = (n + capacity - 1) / capacity;
       sent_slot0[i] = (int)fill.size() * GLR_TILE_WORDS;
       for (int s = 0; s < k; ++s) {
-        fill.push_back(GLR_TILE_WORDS);
+        fill.push_back(capacity);
         members.emplace_back(1, i);
         nsub.push_back(s == 0 ? k : -1);
       }
       continue;
     }
     size_t t = 0;
-    while (t < fill.size() && fill[t] + n > GLR_TILE_WORDS) ++t;   // first fit
+    while (t < fill.size() && fill[t] + n > capacity) ++t;   // first fit
     if (t == fill.size()) { fill.push_back(0); members.emplace_back(); nsub.push_back(0); }
     sent_slot0[i] = (int)t * GLR_TILE_WORDS + fill[t];
     fill[t] += n;
@@ -62,23 +63,35 @@ extern "C" int glr_plan_tiles(const int32_t* cap_lens, int n_sent, int32_t* sent
 namespace {
 
 // grid (S_pad/64, D/64, B), 256 threads: one 64(feature) x 64(region) tile.
-__global__ void __launch_bounds__(256) k_pack_regions(const void* __restrict__ img, int in_dtype,
+// in_layout 0: img [B, D, S] (NCHW, the reference layout) -> transposed through LDS
+// in_layout 1: img [B, S, D] (channels-last memory of the same tensor) -> straight copy
+__global__ void __launch_bounds__(256) k_pack_regions(const void* __restrict__ img, int in_dtype, int in_layout,
                                                       const void* __restrict__ no_attn, void* __restrict__ vt,
-                                                      void* __restrict__ vd, int D, int S, int S_pad, int shift,
-                                                      int op_dtype) {
+                                                      int D, int S, int S_pad, int shift, int op_dtype) {
   __shared__ float tile[64][65];
   const int b = blockIdx.z, d0 = blockIdx.y * 64, r0 = blockIdx.x * 64;
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   const int S_eff = S + shift;
+  if (in_layout == 1) {
+    for (int rl = ty; rl < 64; rl += 4) {
+      const int rp = r0 + rl, d = d0 + tx;            // rp = packed region index
+      float v = 0.f;
+      if (rp < S_eff) {
+        if (shift && rp == 0) v = ld_any(no_attn, d, in_dtype);
+        else v = ld_any(img, ((size_t)b * S + (rp - shift)) * D + d, in_dtype);
+      }
+      st_any(vt, ((size_t)b * S_pad + rp) * D + d, op_dtype, v);
+    }
+    return;
+  }
   for (int dl = ty; dl < 64; dl += 4) {
-    const int d = d0 + dl, rp = r0 + tx;            // rp = packed region index
+    const int d = d0 + dl, rp = r0 + tx;
     float v = 0.f;
     if (rp < S_eff) {
       if (shift && rp == 0) v = ld_any(no_attn, d, in_dtype);
       else v = ld_any(img, ((size_t)b * D + d) * S + (rp - shift), in_dtype);
     }
     tile[dl][tx] = v;
-    st_any(vd, ((size_t)b * D + d) * S_pad + rp, op_dtype, v);
   }
   __syncthreads();
   for (int rl = ty; rl < 64; rl += 4)
@@ -89,7 +102,7 @@ __global__ void __launch_bounds__(256) k_pack_regions(const void* __restrict__ i
 __global__ void __launch_bounds__(256) k_pack_words(const void* __restrict__ words, int in_dtype,
                                                     const int* __restrict__ sent_slot0,
                                                     const int* __restrict__ cap_lens, void* __restrict__ tp, int D,
-                                                    int L, int word_start, int op_dtype) {
+                                                    int L, int word_start, int capacity, int op_dtype) {
   __shared__ float tile[64][65];
   const int i = blockIdx.y, d0 = blockIdx.x * 64;
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
@@ -103,7 +116,11 @@ __global__ void __launch_bounds__(256) k_pack_words(const void* __restrict__ wor
     }
     __syncthreads();
     for (int wl = ty; wl < 64; wl += 4)
-      if (w0 + wl < n) st_any(tp, (size_t)(slot0 + w0 + wl) * D + d0 + tx, op_dtype, tile[tx][wl]);
+      if (w0 + wl < n) {
+        const int w = w0 + wl;          // word w of a multi-tile sentence: tile w / capacity, position w % capacity
+        const size_t slot = (size_t)slot0 + (w / capacity) * GLR_TILE_WORDS + (w % capacity);
+        st_any(tp, slot * D + d0 + tx, op_dtype, tile[tx][wl]);
+      }
     __syncthreads();
   }
 }
@@ -125,30 +142,32 @@ __global__ void __launch_bounds__(256) k_word_norms(const void* __restrict__ tp,
 
 }  // namespace
 
-extern "C" int glr_pack_regions(const void* img_features, int in_dtype, const void* no_attn_vec, void* vt,
-                                void* vd, int B, int D, int S, int op_dtype, void* stream) {
-  if (!img_features || !vt || !vd || B <= 0 || D <= 0 || S <= 0 || D % 64 != 0) return GLR_EINVAL;
+extern "C" int glr_pack_regions(const void* img_features, int in_dtype, int in_layout, const void* no_attn_vec,
+                                void* vt, int B, int D, int S, int op_dtype, void* stream) {
+  if (!img_features || !vt || B <= 0 || D <= 0 || S <= 0 || D % 64 != 0) return GLR_EINVAL;
+  if (in_layout != 0 && in_layout != 1) return GLR_EINVAL;
   if ((in_dtype != GLR_F32 && in_dtype != GLR_BF16) || (op_dtype != GLR_F32 && op_dtype != GLR_BF16)) return GLR_EDTYPE;
   const int shift = no_attn_vec ? 1 : 0;
   const int S_pad = glr_region_pad(S + shift);
   if (S_pad > GLR_MAX_SPAD) return GLR_EINVAL;
   hipLaunchKernelGGL(k_pack_regions, dim3(S_pad / 64, D / 64, B), dim3(256), 0, (hipStream_t)stream, img_features,
-                     in_dtype, no_attn_vec, vt, vd, D, S, S_pad, shift, op_dtype);
+                     in_dtype, in_layout, no_attn_vec, vt, D, S, S_pad, shift, op_dtype);
   GLR_CHECK_LAUNCH();
   return GLR_OK;
 }
 
 extern "C" int glr_pack_words(const void* words_emb, int in_dtype, const int32_t* sent_slot0_dev,
                               const int32_t* cap_lens_dev, void* tp, float* tnorm, int B_txt, int D, int L,
-                              int word_start, int n_slots, int op_dtype, void* stream) {
+                              int word_start, int n_slots, int capacity, int op_dtype, void* stream) {
   if (!words_emb || !sent_slot0_dev || !cap_lens_dev || !tp || !tnorm) return GLR_EINVAL;
   if (B_txt <= 0 || D <= 0 || L <= 0 || n_slots <= 0 || D % 64 != 0 || word_start < 0) return GLR_EINVAL;
+  if (capacity != 32 && capacity != GLR_TILE_WORDS) return GLR_EINVAL;
   if ((in_dtype != GLR_F32 && in_dtype != GLR_BF16) || (op_dtype != GLR_F32 && op_dtype != GLR_BF16)) return GLR_EDTYPE;
   hipStream_t st = (hipStream_t)stream;
   const size_t esz = op_dtype == GLR_F32 ? 4 : 2;
   if (hipMemsetAsync(tp, 0, (size_t)n_slots * D * esz, st) != hipSuccess) return GLR_ELAUNCH;
   hipLaunchKernelGGL(k_pack_words, dim3(D / 64, B_txt), dim3(256), 0, st, words_emb, in_dtype, sent_slot0_dev,
-                     cap_lens_dev, tp, D, L, word_start, op_dtype);
+                     cap_lens_dev, tp, D, L, word_start, capacity, op_dtype);
   GLR_CHECK_LAUNCH();
   hipLaunchKernelGGL(k_word_norms, dim3((n_slots + 3) / 4), dim3(256), 0, st, tp, tnorm, n_slots, D, op_dtype);
   GLR_CHECK_LAUNCH();

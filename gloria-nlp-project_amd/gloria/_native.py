@@ -23,15 +23,17 @@ SYMBOLS = {
     # name: (restype, argtypes)
     "glr_version": (c_int, []),
     "glr_region_pad": (c_int, [c_int]),
-    "glr_plan_tiles_bound": (c_int, [c_void_p, c_int]),
-    "glr_plan_tiles": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
-    "glr_pack_regions": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "glr_tile_capacity": (c_int, [c_int]),
+    "glr_plan_tiles_bound": (c_int, [c_void_p, c_int, c_int]),
+    "glr_plan_tiles": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "glr_pack_regions": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "glr_pack_words": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
-                               c_int, c_int, c_void_p]),
-    "glr_local_attn_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                   c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_float, c_float, c_int,
-                                   c_float, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int,
-                                   c_int, c_int, c_void_p]),
+                               c_int, c_int, c_int, c_void_p]),
+    "glr_local_attn_fwd": (c_int, [c_void_p] * 9 + [c_int] * 5 + [c_float] * 3 + [c_int, c_float, c_void_p, c_int,
+                                   c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "glr_local_attn_bwd": (c_int, [c_void_p] * 9 + [c_int] * 5 + [c_float] * 3 + [c_int, c_float, c_void_p, c_void_p,
+                                   c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                   c_void_p]),
     "glr_dual_ce_fwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "glr_dual_ce_bwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "glr_global_sim_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float, c_void_p, c_int,
@@ -93,22 +95,23 @@ def require_cuda(*tensors):
 class TilePlan:
     """Sentence -> word-slot packing (host planning by glr_plan_tiles + device copies)."""
 
-    def __init__(self, cap_lens, device):
+    def __init__(self, cap_lens, device, capacity=TILE_WORDS):
         cl = np.ascontiguousarray(np.asarray(cap_lens, dtype=np.int32))
         n = int(cl.shape[0])
         L = lib()
-        bound = L.glr_plan_tiles_bound(cl.ctypes.data_as(c_void_p), n)
+        bound = L.glr_plan_tiles_bound(cl.ctypes.data_as(c_void_p), n, capacity)
         if bound <= 0:
             raise ValueError(f"cap_lens must be in [1, 512] (glr_plan_tiles_bound -> {bound})")
         slot0 = np.zeros(n, dtype=np.int32)
         tile_first = np.zeros(bound + 1, dtype=np.int32)
         order = np.zeros(bound, dtype=np.int32)
         nsub = np.zeros(bound, dtype=np.int32)
-        nt = L.glr_plan_tiles(cl.ctypes.data_as(c_void_p), n, slot0.ctypes.data_as(c_void_p),
+        nt = L.glr_plan_tiles(cl.ctypes.data_as(c_void_p), n, capacity, slot0.ctypes.data_as(c_void_p),
                               tile_first.ctypes.data_as(c_void_p), order.ctypes.data_as(c_void_p),
                               nsub.ctypes.data_as(c_void_p))
         if nt <= 0:
             raise ValueError(f"glr_plan_tiles failed ({nt})")
+        self.capacity = capacity
         self.cap_lens_host = cl
         self.n_sent, self.n_tiles, self.n_slots = n, nt, nt * TILE_WORDS
         self.sent_slot0_host = slot0
@@ -122,6 +125,17 @@ class TilePlan:
         self.order = dev[o:o + bound]; o += bound
         self.tile_nsub = dev[o:o + nt]
         self._dev = dev
+        self._word_index = None
+
+    def word_index(self, device):
+        """(sentence, word, slot) of every packed word, as device int64 tensors (for scattering the
+        packed word gradient back to [B, D, L])."""
+        if self._word_index is None:
+            si = np.repeat(np.arange(self.n_sent), self.cap_lens_host)
+            wi = np.concatenate([np.arange(n) for n in self.cap_lens_host])
+            slot = self.sent_slot0_host[si].astype(np.int64) + (wi // self.capacity) * TILE_WORDS + wi % self.capacity
+            self._word_index = tuple(torch.from_numpy(a.astype(np.int64)).to(device) for a in (si, wi, slot))
+        return self._word_index
 
     def attn_offsets(self, s_out, device):
         off = np.zeros(self.n_sent + 1, dtype=np.int64)

@@ -59,11 +59,12 @@ class _Opts:
         self.pair_only, self.want_wctx = pair_only, want_wctx
 
 
-def _launch_local(img3, words, no_attn_vec, plan, o):
-    """img3 [B, D, S], words [B_txt, D, L] on the GPU.  Returns sim, attn_flat, wctx."""
+def _pack_operands(img_features, words, no_attn_vec, cap_lens, o):
+    """Operand packing shared by forward and backward: vt, gram, tp, tnorm + the tile plan."""
     L = N.lib()
-    dev = img3.device
-    B, D, S = img3.shape
+    dev = img_features.device
+    B, D = img_features.shape[:2]
+    S = img_features[0, 0].numel()
     shift = 0 if no_attn_vec is None else 1
     s_eff = S + shift
     s_pad = L.glr_region_pad(s_eff)
@@ -71,61 +72,87 @@ def _launch_local(img3, words, no_attn_vec, plan, o):
         raise ValueError(f"{s_eff} regions exceed the kernel limit of {N.MAX_SPAD}")
     if D % 64 != 0:
         raise ValueError(f"embedding dim must be a multiple of 64, got {D}")
-    code = _op_code(img3, words)
+    code = _op_code(img_features, words)
     odt = N.torch_dtype(code)
-    in_code = N.dtype_code(img3.dtype)
-    if words.dtype != img3.dtype:
-        words = words.to(img3.dtype)
-    na = None if no_attn_vec is None else no_attn_vec.detach().to(img3.dtype).contiguous()
+    plan = N.TilePlan(cap_lens, dev, L.glr_tile_capacity(code))
+    # channels-last feature maps already are [B, S, D] in memory: no transpose needed
+    img = img_features
+    layout = 0
+    if img.dim() == 4 and not img.is_contiguous() and img.is_contiguous(memory_format=torch.channels_last):
+        layout = 1
+    else:
+        img = img.contiguous()
+    in_code = N.dtype_code(img.dtype)
+    if words.dtype != img.dtype:
+        words = words.to(img.dtype)
+    words = words.contiguous()
+    na = None if no_attn_vec is None else no_attn_vec.detach().to(img.dtype).contiguous()
     st = N.stream()
     vt = torch.empty(B, s_pad, D, dtype=odt, device=dev)
-    vd = torch.empty(B, D, s_pad, dtype=odt, device=dev)
-    N.check(L.glr_pack_regions(N.ptr(img3), in_code, N.ptr(na), N.ptr(vt), N.ptr(vd), B, D, S, code, st),
+    N.check(L.glr_pack_regions(N.ptr(img), in_code, layout, N.ptr(na), N.ptr(vt), B, D, S, code, st),
             "glr_pack_regions")
+    gram = torch.bmm(vt, vt.transpose(1, 2))            # plain batched GEMM (hipBLASLt): G[b] = V^T V
     tp = torch.empty(plan.n_slots, D, dtype=odt, device=dev)
     tnorm = torch.empty(plan.n_slots, dtype=torch.float32, device=dev)
     N.check(L.glr_pack_words(N.ptr(words), in_code, N.ptr(plan.sent_slot0), N.ptr(plan.cap_lens), N.ptr(tp),
-                             N.ptr(tnorm), words.shape[0], D, words.shape[2], o.word_start, plan.n_slots, code, st),
-            "glr_pack_words")
-    n_sent = plan.n_sent
-    sim = (torch.zeros if o.pair_only else torch.empty)(B, n_sent, dtype=torch.float32, device=dev)
-    attn = attn_off = None
-    s_out = s_eff - shift
-    if o.want_attn:
-        attn_off, off_host = plan.attn_offsets(s_out, dev)
-        attn = torch.zeros(int(off_host[-1]), dtype=torch.float32, device=dev)
-    wctx, ld_wctx = None, 0
-    if o.want_wctx:
-        ld_wctx = int(plan.cap_lens_host.max())
-        wctx = torch.zeros(B, D, ld_wctx, dtype=torch.float32, device=dev)
-    if K1_EVENTS is not None:
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        ev0.record()
-    N.check(L.glr_local_attn_fwd(N.ptr(vt), N.ptr(vd), N.ptr(tp), N.ptr(tnorm), N.ptr(plan.sent_slot0),
-                                 N.ptr(plan.cap_lens), N.ptr(plan.tile_first), N.ptr(plan.order),
-                                 N.ptr(plan.tile_nsub), plan.n_tiles, n_sent, B, D, s_eff, o.temp1, o.temp2,
-                                 o.temp3, N.AGG[o.agg], o.eps, N.ptr(sim), n_sent, N.ptr(attn), N.ptr(attn_off),
-                                 shift, N.ptr(wctx), ld_wctx, 1 if o.pair_only else 0, o.img_offset, code, st),
-            "glr_local_attn_fwd")
-    if K1_EVENTS is not None:
-        ev1.record()
-        n_words = plan.n_words if not o.pair_only else int(plan.cap_lens_host[o.img_offset:o.img_offset + B].sum() // max(B, 1))
-        K1_EVENTS.append((ev0, ev1, (4.0 * s_eff * D + 6.0 * D) * B * n_words))
-    return sim, attn, wctx
+                             N.ptr(tnorm), words.shape[0], D, words.shape[2], o.word_start, plan.n_slots,
+                             plan.capacity, code, st), "glr_pack_words")
+    return plan, code, vt, gram, tp, tnorm, s_eff, s_pad, shift
+
+
+def _k1_args(plan, vt, gram, tp, tnorm, B, D, s_eff, o):
+    return (N.ptr(vt), N.ptr(gram), N.ptr(tp), N.ptr(tnorm), N.ptr(plan.sent_slot0), N.ptr(plan.cap_lens),
+            N.ptr(plan.tile_first), N.ptr(plan.order), N.ptr(plan.tile_nsub), plan.n_tiles, plan.n_sent, B, D,
+            s_eff, o.temp1, o.temp2, o.temp3, N.AGG[o.agg], o.eps)
 
 
 class LocalSimFn(torch.autograd.Function):
-    """sim[b, i] for local images x all sentences (+ diagonal attention maps), HIP forward."""
+    """sim[b, i] for local images x all sentences (+ diagonal attention maps).  HIP forward (K1) and
+    HIP backward (K1 bwd + three plain GEMMs); the gradient THROUGH THE ATTENTION MAPS themselves
+    (attention-supervision loss, attention_fn outputs) still uses the torch restatement of the B
+    diagonal pairs in loss/_recompute.py."""
 
     @staticmethod
-    def forward(ctx, img_features, words_emb, no_attn_vec, plan, opts):
+    def forward(ctx, img_features, words_emb, no_attn_vec, cap_lens, opts):
         N.require_cuda(img_features, words_emb, no_attn_vec)
-        B, D = img_features.shape[:2]
-        img3 = _as_supported(img_features.detach()).reshape(B, D, -1)
+        L = N.lib()
+        o = opts
+        img = _as_supported(img_features.detach()) if img_features.dtype not in (torch.float32, torch.bfloat16) \
+            else img_features.detach()
         words = _as_supported(words_emb.detach())
-        sim, attn, wctx = _launch_local(img3, words, no_attn_vec, plan, opts)
-        ctx.save_for_backward(img_features, words_emb, no_attn_vec)
-        ctx.plan, ctx.opts = plan, opts
+        plan, code, vt, gram, tp, tnorm, s_eff, s_pad, shift = _pack_operands(img, words, no_attn_vec, cap_lens, o)
+        dev = img.device
+        B, D = img.shape[:2]
+        n_sent = plan.n_sent
+        need_grad = any(t is not None and t.requires_grad for t in (img_features, words_emb, no_attn_vec)) \
+            and not o.pair_only
+        sim = (torch.zeros if o.pair_only else torch.empty)(B, n_sent, dtype=torch.float32, device=dev)
+        lse = torch.empty(B, n_sent, s_pad, dtype=torch.float32, device=dev) if need_grad else None
+        wstat = torch.empty(B, plan.n_slots, 4, dtype=torch.float32, device=dev) if need_grad else None
+        attn = attn_off = None
+        strip = 0 if o.want_wctx else shift
+        if o.want_attn:
+            attn_off, off_host = plan.attn_offsets(s_eff - strip, dev)
+            attn = torch.zeros(int(off_host[-1]), dtype=torch.float32, device=dev)
+        if K1_EVENTS is not None:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
+        N.check(L.glr_local_attn_fwd(*_k1_args(plan, vt, gram, tp, tnorm, B, D, s_eff, o), N.ptr(sim), n_sent,
+                                     N.ptr(lse), N.ptr(wstat), N.ptr(attn), N.ptr(attn_off), strip,
+                                     1 if o.pair_only else 0, o.img_offset, code, N.stream()),
+                "glr_local_attn_fwd")
+        if K1_EVENTS is not None:
+            ev1.record()
+            n_words = plan.n_words if not o.pair_only else plan.n_words // max(n_sent, 1)
+            K1_EVENTS.append((ev0, ev1, (4.0 * s_eff * D + 6.0 * D) * B * n_words))
+        wctx = None
+        if o.want_wctx:      # attention_fn's first output: V . a2^T for the B diagonal pairs (plain bmm)
+            n = int(plan.cap_lens_host[0])
+            a2 = attn.view(B, n, s_eff)
+            wctx = torch.bmm(a2.to(vt.dtype), vt[:, :s_eff]).transpose(1, 2).float().contiguous()   # [B, D, n]
+            attn = a2[:, :, shift:].contiguous().view(-1)
+        ctx.save_for_backward(img_features, words_emb, no_attn_vec, vt, gram, tp, tnorm, sim, lse, wstat)
+        ctx.plan, ctx.opts, ctx.meta = plan, o, (code, s_eff, s_pad, shift)
         ctx.set_materialize_grads(False)       # unused outputs (maps, context) arrive as None
         if attn is None:
             attn = sim.new_zeros(0)
@@ -135,52 +162,65 @@ class LocalSimFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dsim, dattn, dwctx):
-        img_features, words_emb, no_attn_vec = ctx.saved_tensors
+        img_features, words_emb, no_attn_vec, vt, gram, tp, tnorm, sim, lse, wstat = ctx.saved_tensors
         plan, o = ctx.plan, ctx.opts
+        code, s_eff, s_pad, shift = ctx.meta
+        L = N.lib()
         dev = img_features.device
         B, D = img_features.shape[:2]
-        img = img_features.detach().float().reshape(B, D, -1)
-        words = words_emb.detach().float().requires_grad_(True)
-        na = None if no_attn_vec is None else no_attn_vec.detach().float().requires_grad_(True)
-        si = torch.from_numpy(np.repeat(np.arange(plan.n_sent), plan.cap_lens_host)).to(dev)
-        wi = torch.from_numpy(np.concatenate([np.arange(n) for n in plan.cap_lens_host]) + o.word_start).to(dev)
-        capf = torch.from_numpy(plan.cap_lens_host.astype(np.float32)).to(dev)
-        d_img = torch.zeros_like(img)
-        s_eff = img.shape[2] + (0 if na is None else 1)
-        # images per chunk so that ~12 live [chunk, S, N] fp32 tensors stay near 2 GB
-        chunk = max(1, min(B, int(2e9 / (12.0 * 4 * s_eff * max(plan.n_words, 1)))))
+        d_img = torch.zeros(B, D, s_eff - shift, dtype=torch.float32, device=dev)
+        d_words = torch.zeros(words_emb.shape, dtype=torch.float32, device=dev)
+        d_na = None if no_attn_vec is None else torch.zeros(D, dtype=torch.float32, device=dev)
+
+        if dsim is not None and not o.pair_only:
+            if lse is None:
+                raise RuntimeError("local similarity was computed without gradient state")
+            odt = vt.dtype
+            ns = plan.n_slots
+            xout = torch.empty(ns, B, s_pad, dtype=odt, device=dev)
+            bout = torch.empty(B, ns, s_pad, dtype=odt, device=dev)
+            aout = torch.empty(B, ns, s_pad, dtype=odt, device=dev)
+            gamma = torch.empty(B, ns, dtype=torch.float32, device=dev)
+            g = dsim.float().contiguous()
+            N.check(L.glr_local_attn_bwd(*_k1_args(plan, vt, gram, tp, tnorm, B, D, s_eff, o), N.ptr(sim), N.ptr(g),
+                                         plan.n_sent, N.ptr(lse), N.ptr(wstat), N.ptr(xout), N.ptr(bout),
+                                         N.ptr(aout), N.ptr(gamma), code, N.stream()), "glr_local_attn_bwd")
+            # gradient GEMMs (plain library GEMMs on the kernel's outputs)
+            x2d = xout.view(ns, B * s_pad)
+            dtp = (x2d @ vt.view(B * s_pad, D)).float() - gamma.sum(0).unsqueeze(1) * tp.float()      # [ns, D]
+            P = torch.bmm(bout.transpose(1, 2), aout)                                                  # [B, S, S]
+            dvt = (x2d.t() @ tp).view(B, s_pad, D).float() - torch.bmm(P, vt).float()                 # [B, S, D]
+            si, wi, slot = plan.word_index(dev)
+            d_words.permute(0, 2, 1)[si, wi + o.word_start] = dtp[slot]
+            d_img += dvt[:, shift:s_eff].transpose(1, 2)
+            if d_na is not None:
+                d_na += dvt[:, 0].sum(0)
+
         need_attn = o.want_attn and dattn is not None and dattn.numel() > 0
         need_wctx = o.want_wctx and dwctx is not None and dwctx.numel() > 0
-        with torch.enable_grad():
-            T = words.permute(0, 2, 1)[si, wi]                          # [N, D]
-            if dsim is not None and not o.pair_only:
-                for b0 in range(0, B, chunk):
-                    vc = img[b0:b0 + chunk].clone().requires_grad_(True)
-                    V = vc if na is None else torch.cat([na.view(1, D, 1).expand(vc.shape[0], D, 1), vc], 2)
-                    sim_c, _ = R.local_sim_packed(V, T, si, capf, o.temp1, o.temp2, o.temp3, o.agg, o.eps)
-                    sim_c.backward(dsim[b0:b0 + chunk].float(), retain_graph=True)
-                    d_img[b0:b0 + chunk] = vc.grad
-            if need_attn or need_wctx or (dsim is not None and o.pair_only):
-                # diagonal pairs only (attention maps / attention_fn outputs): B small problems
+        if need_attn or need_wctx:
+            # gradient through the attention maps of the B diagonal pairs (torch restatement, small)
+            img = img_features.detach().float().reshape(B, D, -1)
+            words = words_emb.detach().float().requires_grad_(True)
+            na = None if no_attn_vec is None else no_attn_vec.detach().float().requires_grad_(True)
+            with torch.enable_grad():
                 vc = img.clone().requires_grad_(True)
                 V = vc if na is None else torch.cat([na.view(1, D, 1).expand(B, D, 1), vc], 2)
                 lens = plan.cap_lens_host[o.img_offset:o.img_offset + B]
-                wloc = words[o.img_offset:o.img_offset + B]
-                a2 = R.diag_attention(V, wloc, lens, o.word_start, o.temp1)     # [B, Lmax, S_eff]
+                a2 = R.diag_attention(V, words[o.img_offset:o.img_offset + B], lens, o.word_start, o.temp1)
                 loss = 0.0
-                shift = 0 if na is None else 1
                 if need_attn:
                     flat = torch.cat([a2[b, :int(lens[b]), shift:].reshape(-1) for b in range(B)])
                     off0 = int((plan.cap_lens_host[:o.img_offset].astype(np.int64) * (s_eff - shift)).sum())
                     loss = loss + (flat * dattn[off0:off0 + flat.numel()].float()).sum()
                 if need_wctx:
-                    ctxv = torch.einsum("bdr,bwr->bdw", V, a2)                  # [B, D, Lmax]
+                    ctxv = torch.einsum("bdr,bwr->bdw", V, a2)
                     loss = loss + (ctxv * dwctx[:, :, :ctxv.shape[2]].float()).sum()
-                if torch.is_tensor(loss):
-                    loss.backward()
-                    d_img += vc.grad
-        d_words = words.grad if words.grad is not None else torch.zeros_like(words)
-        d_na = None if na is None else (na.grad if na.grad is not None else torch.zeros_like(na))
+                loss.backward()
+            d_img += vc.grad
+            d_words += words.grad
+            if na is not None and na.grad is not None:
+                d_na += na.grad
         return (d_img.reshape(img_features.shape).to(img_features.dtype), d_words.to(words_emb.dtype),
                 None if d_na is None else d_na.to(no_attn_vec.dtype), None, None)
 
@@ -287,9 +327,8 @@ def attention_fn(query, context, temp1, no_attn_vec=None):
     """
     B, D, n = query.shape
     ih, iw = context.size(2), context.size(3)
-    plan = N.TilePlan([n] * B, query.device)
     opts = _Opts(temp1, 1.0, 1.0, "sum", 1e-8, True, 0, 0, True, True)
-    _, attn, wctx = LocalSimFn.apply(context, query, no_attn_vec, plan, opts)
+    _, attn, wctx = LocalSimFn.apply(context, query, no_attn_vec, [n] * B, opts)
     return wctx[:, :, :n].to(query.dtype), attn.view(B, n, ih, iw).to(query.dtype)
 
 
@@ -303,11 +342,10 @@ def global_loss(cnn_code, rnn_code, eps=1e-8, temp3=10.0):
 
 def local_similarity(img_features, words_emb, cap_lens: Sequence[int], temp1=4.0, temp2=5.0, temp3=10.0,
                      agg="sum", no_attn_vec=None, eps=1e-8, want_attn=True, img_offset=0, word_start=0):
-    """B_img x n_sent similarity matrix (already * temp3) + flat diagonal attention maps + plan."""
-    plan = N.TilePlan([int(c) for c in cap_lens], img_features.device)
+    """B_img x n_sent similarity matrix (already * temp3) + flat diagonal attention maps."""
     opts = _Opts(temp1, temp2, temp3, agg, eps, want_attn, img_offset, word_start, False, False)
-    sim, attn, _ = LocalSimFn.apply(img_features, words_emb, no_attn_vec, plan, opts)
-    return sim, attn, plan
+    sim, attn, _ = LocalSimFn.apply(img_features, words_emb, no_attn_vec, [int(c) for c in cap_lens], opts)
+    return sim, attn, None
 
 
 def split_attention_maps(attn_flat, cap_lens, ih, iw, first=0, count=None) -> List[torch.Tensor]:

@@ -51,15 +51,22 @@ int glr_version(void);
 /* Padded region count used by the packed operand layouts: S_eff rounded up to a multiple of 64. */
 int glr_region_pad(int s_eff);
 
+/* Populated word slots per 64-slot tile for an operand dtype: 64 (GLR_BF16) or 32 (GLR_F32: the
+ * fp32 score tile and fp32 attention image of 64 words do not fit the 160 KB LDS together). */
+int glr_tile_capacity(int op_dtype);
+
 /* ------------------------------------------------------------------------------------------
  * Host-side planning: pack sentences into tiles of GLR_TILE_WORDS word slots.
  * Replaces the per-sentence slicing `words_emb[i, :, :cap_lens[i]]` of the reference loop
  * (gloria_loss.py:116-123): sentence i occupies cap_lens[i] consecutive slots.  A sentence of at
- * most GLR_TILE_WORDS words lies inside one tile (first fit, in the given order); a longer one
- * owns ceil(n / GLR_TILE_WORDS) consecutive tiles of its own.
+ * most `capacity` words lies inside one tile (first fit, in the given order, at most `capacity`
+ * populated slots per tile); a longer one owns ceil(n / capacity) consecutive tiles of its own.
  *
  *   cap_lens[n_sent]    words per sentence (1..GLR_MAX_WORDS)
- *   sent_slot0[n_sent]  out: global slot of the sentence's first word (tile * GLR_TILE_WORDS + pos)
+ *   capacity            glr_tile_capacity(op_dtype)
+ *   sent_slot0[n_sent]  out: global slot of the sentence's first word (tile * GLR_TILE_WORDS + pos);
+ *                       word w of a multi-tile sentence sits at slot0 + (w / capacity) * GLR_TILE_WORDS
+ *                       + w % capacity
  *   tile_first[cap]     out: for tile t, index of its first sentence in `order`; [n_tiles] = end.
  *                       Must hold (upper bound on tiles) + 1 ints; glr_plan_tiles_bound gives it.
  *   order[cap]          out: sentence ids in tile order (a multi-tile sentence appears once per tile)
@@ -67,65 +74,82 @@ int glr_region_pad(int s_eff);
  *                       continuation tiles
  * returns the number of tiles (>0) or a negative error.
  */
-int glr_plan_tiles_bound(const int32_t* cap_lens, int n_sent);
-int glr_plan_tiles(const int32_t* cap_lens, int n_sent, int32_t* sent_slot0, int32_t* tile_first,
-                   int32_t* order, int32_t* tile_nsub);
+int glr_plan_tiles_bound(const int32_t* cap_lens, int n_sent, int capacity);
+int glr_plan_tiles(const int32_t* cap_lens, int n_sent, int capacity, int32_t* sent_slot0,
+                   int32_t* tile_first, int32_t* order, int32_t* tile_nsub);
 
 /* ------------------------------------------------------------------------------------------
  * Operand packing (device).  HBM-bound layout/convert kernels.
  *
- * glr_pack_regions: img_features [B, D, S] (in_dtype) -> two operand copies in op_dtype
- *     vt [B, S_pad, D]  (region-major, feature contiguous: B^T operand of the score GEMM)
- *     vd [B, D, S_pad]  (feature-major, region contiguous: A operand of the context GEMM)
- *   With no_attn_vec != NULL ([D], in_dtype) a learned column is PREPENDED (region 0), i.e.
- *   S_eff = S + 1 (gloria_loss.py:31-34).  Regions [S_eff, S_pad) are zero.
+ * glr_pack_regions: img_features -> vt [B, S_pad, D] in op_dtype (region-major, feature
+ *   contiguous: the B^T operand of the score contraction).  in_layout 0: img_features is
+ *   [B, D, S] (NCHW, what the reference passes); in_layout 1: [B, S, D] (the same tensor in
+ *   channels-last memory).  With no_attn_vec != NULL ([D], in_dtype) a learned column is PREPENDED
+ *   (region 0), i.e. S_eff = S + 1 (gloria_loss.py:31-34).  Regions [S_eff, S_pad) are zero.
+ *   This replaces context.view + cat + transpose(1,2).contiguous() of attention_fn (:30-35), once
+ *   per step instead of once per sentence.
+ *   The Gram matrices gram[b] = vt[b] . vt[b]^T ([B, S_pad, S_pad], op_dtype) the kernels also need
+ *   are a plain batched GEMM left to the caller's BLAS (hipBLASLt via torch.bmm in the Python host).
  *
  * glr_pack_words: words_emb [B_txt, D, L] (in_dtype) -> tp [n_slots, D] (op_dtype), word-major,
- *   slot sent_slot0[i] + w  <-  words_emb[i, :, word_start + w] for w < cap_lens[i]
- *   (gloria_loss.py:122; word_start = 1 is the inference slice of gloria_model.py:179).
+ *   word w of sentence i <- words_emb[i, :, word_start + w] for w < cap_lens[i], at the slot given
+ *   by the plan (gloria_loss.py:122; word_start = 1 is the inference slice of gloria_model.py:179).
  *   Unused slots are zero.  tnorm[n_slots] (fp32) = L2 norm of each packed word as rounded to
  *   op_dtype (gloria_loss.py:14).
  */
-int glr_pack_regions(const void* img_features, int in_dtype, const void* no_attn_vec, void* vt, void* vd,
+int glr_pack_regions(const void* img_features, int in_dtype, int in_layout, const void* no_attn_vec, void* vt,
                      int B, int D, int S, int op_dtype, void* stream);
 
 int glr_pack_words(const void* words_emb, int in_dtype, const int32_t* sent_slot0_dev,
                    const int32_t* cap_lens_dev, void* tp, float* tnorm, int B_txt, int D, int L,
-                   int word_start, int n_slots, int op_dtype, void* stream);
+                   int word_start, int n_slots, int capacity, int op_dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------
- * K1  glr_local_attn_fwd - fused region x word attention + cosine + log-sum-exp.
- * Replaces, for ALL image x sentence pairs at once, the body of the reference sentence loop:
- * attention_fn (gloria_loss.py:19-63), cosine_similarity (:11-16) and the exp/sum/log of
- * local_loss (:150-158, :164).
+ * K1  glr_local_attn_fwd / glr_local_attn_bwd - fused region x word attention + cosine +
+ * log-sum-exp and its gradient.  Replaces, for ALL image x sentence pairs at once, the body of the
+ * reference sentence loop: attention_fn (gloria_loss.py:19-63), cosine_similarity (:11-16) and the
+ * exp/sum/log of local_loss (:150-158, :164), and torch autograd through them.
  *
  *   sim[b, i] = temp3 * log( agg_w exp(temp2 * cos(T[i,:,w], c[b,i,w,:])) )
  *
- * One workgroup per (image b, word tile); see DESIGN.md for the kernel anatomy.
+ * One workgroup per (image b, word tile); kernel anatomy in DESIGN.md.
  *
- *   vt, vd       packed regions of the B_img LOCAL images (glr_pack_regions)
+ *   vt, gram     packed regions of the B_img LOCAL images and their Gram matrices
  *   tp, tnorm    packed words of ALL sentences (glr_pack_words)
  *   sent_slot0, cap_lens   [n_sent] device int32 (same arrays as given to glr_pack_words)
  *   tile_first, order, tile_nsub   device int32 copies of the glr_plan_tiles outputs
- *   sim          out fp32 [B_img, ld_sim]; column = sentence id
+ *   sim          fp32 [B_img, ld_sim]; column = sentence id (fwd: out, bwd: in)
+ *   lse          fp32 [B_img, n_sent, S_pad]: log-sum-exp over the words of sentence i of the
+ *                scores of region r (fwd: optional out, needed by bwd)
+ *   wstat        fp32 [B_img, n_slots, 4]: per word Z, cosine, |c|^2, 0 (fwd: optional out, bwd: in)
  *   attn         optional out fp32: attention maps of the DIAGONAL pairs only
  *                (image b with sentence img_offset + b; gloria_loss.py:141-143), packed:
  *                sentence i at attn_off[i] floats, [cap_lens[i], S_eff - strip] row-major where
  *                strip = 1 drops the no-attention column (:60-61).  NULL = not wanted.
- *   wctx         optional out fp32 [B_img, D, ld_wctx]: weighted context of the diagonal pairs
- *                (attention_fn's first return value, :59).  NULL = not wanted.
  *   pair_only    1: launch only the B_img diagonal (image b, tile of sentence img_offset+b) pairs;
- *                sim then only receives the diagonal entries.  Used by attention_fn and by the
- *                attention-finetune configuration, which needs only the maps.
+ *                sim then only receives the diagonal entries (attention_fn, attention-finetune).
  *   img_offset   global index of local image 0 (data-parallel shard offset).
+ *
+ * bwd outputs (operand dtype), consumed by three plain GEMMs on the caller's BLAS:
+ *   xout  [n_slots, B_img, S_pad]   X = ds + alpha*a2 :  dT_packed = X2d . vt2d - gamma_sum * T,
+ *                                                         dvt2d     = X2d^T . tp  - P . vt
+ *   bout, aout [B_img, n_slots, S_pad]   beta*a2 and a2:  P[b] = bout[b]^T . aout[b]
+ *   gamma [B_img, n_slots] fp32          coefficient of T_w in dT (from the word norm)
+ * with X2d = xout viewed [n_slots, B_img*S_pad] and vt2d = vt viewed [B_img*S_pad, D].
  */
-int glr_local_attn_fwd(const void* vt, const void* vd, const void* tp, const float* tnorm,
+int glr_local_attn_fwd(const void* vt, const void* gram, const void* tp, const float* tnorm,
                        const int32_t* sent_slot0, const int32_t* cap_lens, const int32_t* tile_first,
                        const int32_t* order, const int32_t* tile_nsub, int n_tiles, int n_sent, int B_img,
-                       int D, int S_eff,
-                       float temp1, float temp2, float temp3, int agg, float eps, float* sim, int ld_sim,
-                       float* attn, const int64_t* attn_off, int strip, float* wctx, int ld_wctx,
-                       int pair_only, int img_offset, int op_dtype, void* stream);
+                       int D, int S_eff, float temp1, float temp2, float temp3, int agg, float eps,
+                       float* sim, int ld_sim, float* lse, float* wstat, float* attn, const int64_t* attn_off,
+                       int strip, int pair_only, int img_offset, int op_dtype, void* stream);
+
+int glr_local_attn_bwd(const void* vt, const void* gram, const void* tp, const float* tnorm,
+                       const int32_t* sent_slot0, const int32_t* cap_lens, const int32_t* tile_first,
+                       const int32_t* order, const int32_t* tile_nsub, int n_tiles, int n_sent, int B_img,
+                       int D, int S_eff, float temp1, float temp2, float temp3, int agg, float eps,
+                       const float* sim, const float* dsim, int ld_sim, const float* lse, const float* wstat,
+                       void* xout, void* bout, void* aout, float* gamma, int op_dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * K2  dual cross-entropy on a square similarity matrix (labels = arange).
