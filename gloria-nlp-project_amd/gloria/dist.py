@@ -48,6 +48,9 @@ class DistContext:
         self.group = group
         self.rank = dist.get_rank(group)
         self.world_size = dist.get_world_size(group)
+        # GLR_FORCE_DIST=1 runs the sharded code path (all-gather / reduce-scatter / bucketed all-reduce)
+        # even with a single rank: lets one GPU rehearse what the 8-GPU node will execute
+        self.active = self.world_size > 1 or os.environ.get("GLR_FORCE_DIST", "0") == "1"
 
     # -- embeddings
     def all_gather_grad(self, x):
@@ -101,8 +104,13 @@ class DistContext:
 def init_from_env(backend=None):
     """Initialise torch.distributed from RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torchrun)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world <= 1:
+    force = os.environ.get("GLR_FORCE_DIST", "0") == "1"
+    if world <= 1 and not force:
         return None
+    if world <= 1:
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        os.environ.setdefault("MASTER_PORT", "29533")
     if not dist.is_initialized():
         local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         if backend is None:

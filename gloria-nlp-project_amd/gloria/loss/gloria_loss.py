@@ -178,17 +178,17 @@ class LocalSimFn(torch.autograd.Function):
             odt = vt.dtype
             ns = plan.n_slots
             xout = torch.empty(ns, B, s_pad, dtype=odt, device=dev)
-            bout = torch.empty(B, ns, s_pad, dtype=odt, device=dev)
             aout = torch.empty(B, ns, s_pad, dtype=odt, device=dev)
             gamma = torch.empty(B, ns, dtype=torch.float32, device=dev)
+            beta = torch.empty(B, ns, dtype=torch.float32, device=dev)
             g = dsim.float().contiguous()
             N.check(L.glr_local_attn_bwd(*_k1_args(plan, vt, gram, tp, tnorm, B, D, s_eff, o), N.ptr(sim), N.ptr(g),
-                                         plan.n_sent, N.ptr(lse), N.ptr(wstat), N.ptr(xout), N.ptr(bout),
-                                         N.ptr(aout), N.ptr(gamma), code, N.stream()), "glr_local_attn_bwd")
+                                         plan.n_sent, N.ptr(lse), N.ptr(wstat), N.ptr(xout), N.ptr(aout),
+                                         N.ptr(gamma), N.ptr(beta), code, N.stream()), "glr_local_attn_bwd")
             # gradient GEMMs (plain library GEMMs on the kernel's outputs)
             x2d = xout.view(ns, B * s_pad)
             dtp = (x2d @ vt.view(B * s_pad, D)).float() - gamma.sum(0).unsqueeze(1) * tp.float()      # [ns, D]
-            P = torch.bmm(bout.transpose(1, 2), aout)                                                  # [B, S, S]
+            P = torch.bmm((aout * beta.unsqueeze(2).to(odt)).transpose(1, 2), aout)                    # [B, S, S]
             dvt = (x2d.t() @ tp).view(B, s_pad, D).float() - torch.bmm(P, vt).float()                 # [B, S, D]
             si, wi, slot = plan.word_index(dev)
             d_words.permute(0, 2, 1)[si, wi + o.word_start] = dtp[slot]

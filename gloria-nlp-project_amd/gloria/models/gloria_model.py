@@ -99,7 +99,7 @@ class GLoRIA(nn.Module):
 
     def _calc_local_loss(self, img_emb_l, text_emb_l, sents):
         cap_lens = self._cap_lens(sents)
-        if self.dist is not None and self.dist.world_size > 1:
+        if self.dist is not None and self.dist.active:
             return self._calc_local_loss_sharded(img_emb_l, text_emb_l, cap_lens)
         return self.local_loss(
             img_emb_l, text_emb_l, cap_lens, temp1=self.temp1, temp2=self.temp2, temp3=self.temp3,
@@ -124,7 +124,7 @@ class GLoRIA(nn.Module):
         return l0, l1, 0, 0, 0, maps
 
     def _calc_global_loss(self, img_emb_g, text_emb_g):
-        if self.dist is not None and self.dist.world_size > 1:
+        if self.dist is not None and self.dist.active:
             d = self.dist
             txt_all = d.all_gather_grad(text_emb_g)
             sim_rows = GL.global_similarity(img_emb_g, txt_all, temp3=self.temp3)
@@ -147,7 +147,7 @@ class GLoRIA(nn.Module):
             up = nn.functional.interpolate(mean_maps.unsqueeze(1), size=segmentation_labels.shape[1:]).squeeze(1)
             up = up / up.sum(-1, keepdim=True).sum(-2, keepdim=True)
             seg = -torch.log((segmentation_labels * up).sum(-1).sum(-1)).mean()
-            if self.dist is not None and self.dist.world_size > 1:
+            if self.dist is not None and self.dist.active:
                 seg = seg / self.dist.world_size          # mean over the global batch
             loss_ = loss_ + seg * self.segmentation_loss_weight
         loss_ = loss_ + no_attn_loss + kl_loss + entropy_loss

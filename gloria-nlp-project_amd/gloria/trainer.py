@@ -54,7 +54,7 @@ class Trainer:
         loss = out["loss"]
         self.optimizer.zero_grad(set_to_none=True)
         loss.backward()
-        if self.dist is not None and self.dist.world_size > 1:
+        if self.dist is not None and self.dist.active:
             self.dist.allreduce_grads(self.params)
         if self.clip:
             torch.nn.utils.clip_grad_norm_(self.params, self.clip)

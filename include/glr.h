@@ -130,11 +130,12 @@ int glr_pack_words(const void* words_emb, int in_dtype, const int32_t* sent_slot
  *                sim then only receives the diagonal entries (attention_fn, attention-finetune).
  *   img_offset   global index of local image 0 (data-parallel shard offset).
  *
- * bwd outputs (operand dtype), consumed by three plain GEMMs on the caller's BLAS:
- *   xout  [n_slots, B_img, S_pad]   X = ds + alpha*a2 :  dT_packed = X2d . vt2d - gamma_sum * T,
- *                                                         dvt2d     = X2d^T . tp  - P . vt
- *   bout, aout [B_img, n_slots, S_pad]   beta*a2 and a2:  P[b] = bout[b]^T . aout[b]
- *   gamma [B_img, n_slots] fp32          coefficient of T_w in dT (from the word norm)
+ * bwd outputs, consumed by three plain GEMMs on the caller's BLAS:
+ *   xout  [n_slots, B_img, S_pad] op dtype   X = ds + alpha*a2 :
+ *                dT_packed = X2d . vt2d - gamma_sum * T,   dvt2d = X2d^T . tp - P . vt
+ *   aout  [B_img, n_slots, S_pad] op dtype   a2;   beta [B_img, n_slots] fp32 :
+ *                P[b] = (beta[b] * aout[b])^T . aout[b]
+ *   gamma [B_img, n_slots] fp32              coefficient of T_w in dT (from the word norm)
  * with X2d = xout viewed [n_slots, B_img*S_pad] and vt2d = vt viewed [B_img*S_pad, D].
  */
 int glr_local_attn_fwd(const void* vt, const void* gram, const void* tp, const float* tnorm,
@@ -149,7 +150,7 @@ int glr_local_attn_bwd(const void* vt, const void* gram, const void* tp, const f
                        const int32_t* order, const int32_t* tile_nsub, int n_tiles, int n_sent, int B_img,
                        int D, int S_eff, float temp1, float temp2, float temp3, int agg, float eps,
                        const float* sim, const float* dsim, int ld_sim, const float* lse, const float* wstat,
-                       void* xout, void* bout, void* aout, float* gamma, int op_dtype, void* stream);
+                       void* xout, void* aout, float* gamma, float* beta, int op_dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * K2  dual cross-entropy on a square similarity matrix (labels = arange).

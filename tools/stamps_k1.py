@@ -1,0 +1,36 @@
+"""Diagnostic: phase shares of K1 from in-kernel s_memtime stamps (libglr_stamps.so build).
+Never part of the product or bench; read SHARES, not absolute length."""
+import ctypes, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "gloria-nlp-project_amd"))
+import numpy as np, torch
+from gloria import _native as N
+N.LIB_PATH = N.LIB_PATH.replace("libglr.so", "libglr_stamps.so")
+from gloria.loss import gloria_loss as gl
+
+B = 256
+bwd = len(sys.argv) > 1 and sys.argv[1] == "bwd"
+dev = "cuda:0"
+g = torch.Generator(dev).manual_seed(1234)
+img = (torch.randn(B, 768, 19, 19, device=dev, generator=g) * 0.5).bfloat16().requires_grad_(bwd)
+words = (torch.randn(B, 768, 97, device=dev, generator=g) * 0.5).bfloat16().requires_grad_(bwd)
+lens = sorted((int(x) for x in np.random.default_rng(1).integers(5, 41, size=B)), reverse=True)
+L = N.lib()
+L.glr_debug_set_stamps.argtypes = [ctypes.c_void_p]
+grid = 8 * 32 * 100
+buf = torch.zeros(grid * 8, dtype=torch.int64, device=dev)
+def run():
+    sim, _, _ = gl.local_similarity(img, words, lens, want_attn=False)
+    if bwd:
+        l0, l1 = gl.dual_cross_entropy(sim); (l0 + l1).backward()
+run(); torch.cuda.synchronize()
+L.glr_debug_set_stamps(ctypes.c_void_p(buf.data_ptr()))
+run(); torch.cuda.synchronize()
+st = buf.cpu().numpy().reshape(grid, 8)
+st = st[st[:, 0] > 0]
+d = np.diff(st[:, :6].astype(np.float64), axis=1)
+names = ["P1 gemm(T.V^T)", "scores->LDS + walk", "P2 elementwise+image", "P3 gemm(E.G^T)", "P4 epilogue"]
+tot = (st[:, 5] - st[:, 0]).astype(np.float64)
+print(f"{'bwd' if bwd else 'fwd'}: workgroups {len(st)}, median cycles per tile {np.median(tot):.0f} (s_memtime ticks)")
+for i, n in enumerate(names):
+    print(f"  {n:26s} median {np.median(d[:, i]):9.0f}  share {np.median(d[:, i]) / np.median(tot) * 100:5.1f}%")
