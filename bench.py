@@ -93,6 +93,8 @@ def main():
     ap.add_argument("--lengths", default="mix", choices=["mix", "max"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--bert-layers", type=int, default=12)
+    ap.add_argument("--global-batch", type=int, default=GLOBAL_BATCH,
+                    help="experiments only: the metric is defined at the default 256")
     args = ap.parse_args()
 
     from gloria import dist as gdist
@@ -108,14 +110,15 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    assert GLOBAL_BATCH % world == 0
-    per_rank = GLOBAL_BATCH // world
+    GB = args.global_batch
+    assert GB % world == 0
+    per_rank = GB // world
 
     cfg, model, trainer = build(per_rank, args.precision, device, dctx, args.bert_layers)
 
     # synthetic global batch, identical on every rank; rank r takes rows r::world (length-balanced)
-    full = make_batch(GLOBAL_BATCH, seed=1234, lengths=args.lengths)
-    idx = torch.arange(rank, GLOBAL_BATCH, world)
+    full = make_batch(GB, seed=1234, lengths=args.lengths)
+    idx = torch.arange(rank, GB, world)
     batch = {k: v[idx] for k, v in full.items()}
     batch = trainer.to_device(batch)
 
@@ -148,7 +151,7 @@ def main():
     if rank == 0:
         rec = {
             "metric": "image-text pairs/sec (whole node), imagenome_pretrain bs=256",
-            "value": GLOBAL_BATCH * args.steps / elapsed,
+            "value": GB * args.steps / elapsed,
             "unit": "pairs/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -161,7 +164,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": "imagenome_pretrain_config.yaml: ResNet-50 + BERT-base(12L) + local+global "
                                    "contrastive loss, full training step (fwd+bwd+clip+Adam)",
-                       "global_batch": GLOBAL_BATCH, "per_gpu_batch": per_rank, "image": "224x224 -> 299x299",
+                       "global_batch": GB, "per_gpu_batch": per_rank, "image": "224x224 -> 299x299",
                        "tokens": 97, "caption_lengths": args.lengths,
                        "parallelism": f"dp{world}" + (" (text-embedding all-gather + grad all-reduce, RCCL)" if world > 1 else ""),
                        "final_loss": float(loss)},

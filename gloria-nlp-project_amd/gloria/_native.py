@@ -40,6 +40,15 @@ SYMBOLS = {
                                    c_void_p, c_void_p, c_void_p]),
     "glr_global_sim_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                    c_float, c_float, c_void_p, c_void_p, c_void_p]),
+    "glr_wordpiece_segsum_fwd": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                         c_int, c_void_p]),
+    "glr_wordpiece_segsum_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                         c_int, c_void_p]),
+    "glr_attn_sup_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                 c_void_p, c_void_p, c_void_p]),
+    "glr_cosine_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),
+    "glr_cosine_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p,
+                               c_void_p]),
 }
 
 _lib = None

@@ -307,15 +307,39 @@ def global_similarity(cnn_code, rnn_code, eps=1e-8, temp3=10.0):
 # the reference's public functions
 # ------------------------------------------------------------------------------------------
 
+class CosineFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x1, x2, eps):
+        N.require_cuda(x1, x2)
+        a, b = x1.detach().float().contiguous(), x2.detach().float().contiguous()
+        rows, D = a.shape
+        out = torch.empty(rows, dtype=torch.float32, device=a.device)
+        stats = torch.empty(rows, 3, dtype=torch.float32, device=a.device)
+        N.check(N.lib().glr_cosine_fwd(N.ptr(a), N.ptr(b), rows, D, float(eps), N.ptr(out), N.ptr(stats), N.stream()),
+                "glr_cosine_fwd")
+        ctx.save_for_backward(a, b, stats)
+        ctx.eps, ctx.dt = float(eps), (x1.dtype, x2.dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b, stats = ctx.saved_tensors
+        rows, D = a.shape
+        d1, d2 = torch.empty_like(a), torch.empty_like(b)
+        N.check(N.lib().glr_cosine_bwd(N.ptr(a), N.ptr(b), N.ptr(stats), N.ptr(g.float().contiguous()), rows, D,
+                                       ctx.eps, N.ptr(d1), N.ptr(d2), N.stream()), "glr_cosine_bwd")
+        return d1.to(ctx.dt[0]), d2.to(ctx.dt[1]), None
+
+
 def cosine_similarity(x1, x2, dim=1, eps=1e-8):
     """Returns cosine similarity between x1 and x2, computed along dim (ref :11-16: the clamp is
-    applied to the product of the norms).  Thin elementwise helper kept for API parity; inside
-    local_loss the cosine is fused into the K1 epilogue."""
+    applied to the product of the norms).  Inside local_loss the cosine is fused into K1; this
+    standalone entry point (used by the retrieval / inference helpers) runs glr_cosine_fwd/bwd."""
     N.require_cuda(x1, x2)
-    w12 = torch.sum(x1 * x2, dim)
-    w1 = torch.norm(x1, 2, dim)
-    w2 = torch.norm(x2, 2, dim)
-    return (w12 / (w1 * w2).clamp(min=eps)).squeeze()
+    a, b = x1.movedim(dim, -1), x2.movedim(dim, -1)
+    shape = a.shape[:-1]
+    out = CosineFn.apply(a.reshape(-1, a.shape[-1]), b.reshape(-1, b.shape[-1]), eps)
+    return out.view(shape).to(x1.dtype).squeeze()
 
 
 def attention_fn(query, context, temp1, no_attn_vec=None):
@@ -348,10 +372,57 @@ def local_similarity(img_features, words_emb, cap_lens: Sequence[int], temp1=4.0
     return sim, attn, None
 
 
+class AttentionMaps(list):
+    """The reference's list of [1, n_i, ih, iw] attention maps, plus the flat buffer they are views
+    of (so the attention-supervision kernel can consume them without re-packing)."""
+    flat = None
+    cap_lens = None
+    first = 0
+    hw = (0, 0)
+
+
+class AttnSupFn(torch.autograd.Function):
+    """mean_b -log sum(label_b * normalised nearest-upsampled mean attention)  (K4, ref gloria_model.py:143-147)."""
+
+    @staticmethod
+    def forward(ctx, attn_flat, labels, cap_lens, first, count, ih, iw):
+        N.require_cuda(attn_flat, labels)
+        dev = attn_flat.device
+        cl = np.asarray(cap_lens, dtype=np.int64)
+        off = np.zeros(len(cl) + 1, dtype=np.int64)
+        np.cumsum(cl * ih * iw, out=off[1:])
+        off_d = torch.from_numpy(off[:-1].copy()).to(dev)
+        cl_d = torch.from_numpy(cl.astype(np.int32)).to(dev)
+        lab = labels.detach().to(torch.uint8).contiguous()
+        a = attn_flat.detach().float().contiguous()
+        loss_b = torch.empty(count, dtype=torch.float32, device=dev)
+        dmap = torch.zeros_like(a)
+        N.check(N.lib().glr_attn_sup_fwd(N.ptr(a), N.ptr(off_d), N.ptr(cl_d), int(first), N.ptr(lab), int(count),
+                                         lab.shape[1], lab.shape[2], ih, iw, N.ptr(loss_b), N.ptr(dmap), N.stream()),
+                "glr_attn_sup_fwd")
+        ctx.save_for_backward(dmap)
+        ctx.count = count
+        return loss_b.mean()
+
+    @staticmethod
+    def backward(ctx, g):
+        (dmap,) = ctx.saved_tensors
+        return dmap * (g / ctx.count), None, None, None, None, None, None
+
+
+def attention_supervision_loss(att_maps, segmentation_labels):
+    """-log sum(label * U / sum U).mean() over the local diagonal pairs, U the nearest-upsampled
+    word-mean attention map (ref gloria_model.py:143-147), from the flat map buffer (K4)."""
+    ih, iw = att_maps.hw
+    return AttnSupFn.apply(att_maps.flat, segmentation_labels, att_maps.cap_lens, att_maps.first, len(att_maps),
+                           ih, iw)
+
+
 def split_attention_maps(attn_flat, cap_lens, ih, iw, first=0, count=None) -> List[torch.Tensor]:
     """flat diagonal maps -> the reference's list of [1, n_i, ih, iw] tensors (ref :141-143)."""
     count = len(cap_lens) if count is None else count
-    maps, off = [], int(sum(int(c) for c in cap_lens[:first])) * ih * iw
+    maps, off = AttentionMaps(), int(sum(int(c) for c in cap_lens[:first])) * ih * iw
+    maps.flat, maps.cap_lens, maps.first, maps.hw = attn_flat, [int(c) for c in cap_lens], first, (ih, iw)
     for i in range(first, first + count):
         n = int(cap_lens[i])
         maps.append(attn_flat[off:off + n * ih * iw].view(1, n, ih, iw))

@@ -143,10 +143,13 @@ class GLoRIA(nn.Module):
             loss_ = loss_ + (g_loss0 + g_loss1) * self.global_loss_weight
         if segmentation_labels is not None and self.segmentation_loss_weight:
             # attention-supervision term (ref :143-147)
-            mean_maps = torch.cat([m.mean(1) for m in attn_maps], 0)
-            up = nn.functional.interpolate(mean_maps.unsqueeze(1), size=segmentation_labels.shape[1:]).squeeze(1)
-            up = up / up.sum(-1, keepdim=True).sum(-2, keepdim=True)
-            seg = -torch.log((segmentation_labels * up).sum(-1).sum(-1)).mean()
+            if getattr(attn_maps, "flat", None) is not None and attn_maps.flat.is_cuda:
+                seg = GL.attention_supervision_loss(attn_maps, segmentation_labels)          # K4
+            else:
+                mean_maps = torch.cat([m.mean(1) for m in attn_maps], 0)
+                up = nn.functional.interpolate(mean_maps.unsqueeze(1), size=segmentation_labels.shape[1:]).squeeze(1)
+                up = up / up.sum(-1, keepdim=True).sum(-2, keepdim=True)
+                seg = -torch.log((segmentation_labels * up).sum(-1).sum(-1)).mean()
             if self.dist is not None and self.dist.active:
                 seg = seg / self.dist.world_size          # mean over the global batch
             loss_ = loss_ + seg * self.segmentation_loss_weight

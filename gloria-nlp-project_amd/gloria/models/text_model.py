@@ -122,6 +122,43 @@ def wordpiece_slots(ids: np.ndarray, vocab: Vocab):
     return dst, starts, n_words
 
 
+class WordpieceSegSumFn(torch.autograd.Function):
+    """K5: (hidden states of the last layers, token -> word-slot index) -> word_emb [B, D, L], sent_emb [B, D]."""
+
+    @staticmethod
+    def forward(ctx, dst, mean_layers, *layers):
+        from .. import _native as N
+        import ctypes
+        hs = [h.detach().contiguous() for h in layers]
+        if hs[0].dtype not in (torch.float32, torch.bfloat16):
+            hs = [h.float() for h in hs]
+        B, L, D = hs[0].shape
+        dev = hs[0].device
+        word = torch.empty(B, D, L, dtype=torch.float32, device=dev)
+        sent = torch.empty(B, D, dtype=torch.float32, device=dev)
+        ptrs = (ctypes.c_void_p * len(hs))(*[h.data_ptr() for h in hs])
+        N.check(N.lib().glr_wordpiece_segsum_fwd(ptrs, len(hs), N.dtype_code(hs[0].dtype), N.ptr(dst), N.ptr(word),
+                                                 N.ptr(sent), B, L, D, 1 if mean_layers else 0, N.stream()),
+                "glr_wordpiece_segsum_fwd")
+        ctx.save_for_backward(dst)
+        ctx.meta = (B, L, D, len(hs), mean_layers, [h.dtype for h in layers])
+        return word, sent
+
+    @staticmethod
+    def backward(ctx, d_word, d_sent):
+        from .. import _native as N
+        (dst,) = ctx.saved_tensors
+        B, L, D, nl, mean_layers, dts = ctx.meta
+        dw = None if d_word is None else d_word.float().contiguous()
+        ds = None if d_sent is None else d_sent.float().contiguous()
+        out_dt = torch.bfloat16 if dts[0] == torch.bfloat16 else torch.float32
+        dh = torch.empty(B, L, D, dtype=out_dt, device=dst.device)
+        N.check(N.lib().glr_wordpiece_segsum_bwd(N.ptr(dw), N.ptr(ds), N.ptr(dst), N.ptr(dh), N.dtype_code(out_dt),
+                                                 B, L, D, nl, 1 if mean_layers else 0, N.stream()),
+                "glr_wordpiece_segsum_bwd")
+        return (None, None) + tuple(dh.to(dt) for dt in dts)
+
+
 class BertEncoder(nn.Module):
     def __init__(self, cfg):
         super().__init__()
@@ -172,22 +209,31 @@ class BertEncoder(nn.Module):
 
     def forward(self, ids, attn_mask, token_type):
         outputs = self.model(ids, attn_mask, token_type)
+        fused = None
         if self.last_n_layers > 1:
             layers = outputs[2][-self.last_n_layers:]
-            if self.aggregate_method == "sum":
-                embeddings = torch.stack(layers).sum(0)
-            elif self.aggregate_method == "mean":
-                embeddings = torch.stack(layers).mean(0)
-            else:
+            if self.aggregate_method not in ("sum", "mean"):
                 print(self.aggregate_method)
                 raise Exception("Aggregation method not implemented")
-            if self.agg_tokens:
-                word_embeddings, sents = self.aggregate_tokens(embeddings, ids)
-            else:
-                word_embeddings = embeddings
+            if self.agg_tokens and layers[0].is_cuda and self.last_n_layers <= 4 and layers[0].shape[2] % 64 == 0:
+                # K5: segment-sum fused with the layer reduction and the L-mean, [B, D, L] written directly
                 host = ids.detach().cpu().numpy()
-                sents = [[self.vocab.tokens[int(w)] for w in sent] for sent in host]
-            sent_embeddings = word_embeddings.mean(dim=1)          # over ALL L slots (ref :110)
+                B, L = host.shape
+                dst, starts, n_words = wordpiece_slots(host, self.vocab)
+                sents = SentenceBatch(host, dst, starts, n_words, self.vocab, L)
+                dst_d = torch.from_numpy(dst.astype(np.int32)).to(layers[0].device, non_blocking=True)
+                fused = WordpieceSegSumFn.apply(dst_d, self.aggregate_method == "mean", *layers)
+                word_embeddings = fused[0].permute(0, 2, 1)        # [B, L, D] view; permuted back below
+                sent_embeddings = fused[1]
+            else:
+                embeddings = torch.stack(layers).sum(0) if self.aggregate_method == "sum" else torch.stack(layers).mean(0)
+                if self.agg_tokens:
+                    word_embeddings, sents = self.aggregate_tokens(embeddings, ids)
+                else:
+                    word_embeddings = embeddings
+                    host = ids.detach().cpu().numpy()
+                    sents = [[self.vocab.tokens[int(w)] for w in sent] for sent in host]
+                sent_embeddings = word_embeddings.mean(dim=1)          # over ALL L slots (ref :110)
         else:
             word_embeddings, sent_embeddings = outputs[0], outputs[1]
             host = ids.detach().cpu().numpy()

@@ -180,6 +180,42 @@ int glr_global_sim_bwd(const float* img, const float* txt, const float* ni, cons
                        const float* dsim, int ld_sim, int B_img, int B_txt, int D, float temp3, float eps,
                        float* dimg, float* dtxt, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * K5  word-piece -> word aggregation (segment sum) fused with the reduction over the last BERT layers
+ * and the mean over the L word slots.  Replaces BertEncoder.aggregate_tokens + the post-processing of
+ * BertEncoder.forward (gloria/models/text_model.py:32-90, 96-131).
+ *   hidden[n_layers]  device pointers to [B, L, D] hidden states (in_dtype), n_layers <= 4
+ *   dst [B, L] int32  word slot of every token (-1 = dropped), computed on the host from the ids
+ *   word_emb [B, D, L] fp32 (the layout local_loss takes), sent_emb [B, D] fp32
+ *   mean_layers       0: sum over layers (aggregate_method 'sum'), 1: mean
+ * bwd: d_hidden [B, L, D] (out_dtype) is the gradient for EVERY one of the n_layers inputs.
+ */
+int glr_wordpiece_segsum_fwd(const void* const* hidden, int n_layers, int in_dtype, const int32_t* dst,
+                             float* word_emb, float* sent_emb, int B, int L, int D, int mean_layers, void* stream);
+int glr_wordpiece_segsum_bwd(const float* d_word, const float* d_sent, const int32_t* dst, void* d_hidden,
+                             int out_dtype, int B, int L, int D, int n_layers, int mean_layers, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K4  attention-supervision loss on the diagonal attention maps (gloria/models/gloria_model.py:143-147):
+ *   loss_b[b] = -log( sum(label_b * U_b) / sum(U_b) ),  U_b = nearest-upsample(mean_w attn_b[w]) to Hl x Wl,
+ * computed from per-region label pixel counts, never materialising U.  attn / attn_off / cap_lens are
+ * the packed diagonal maps as written by glr_local_attn_fwd (strip applied, S = ih*iw per row).
+ * dmap (optional, same packing): d loss_b / d attn element (multiply by weight / B upstream).
+ * labels: [B, Hl, Wl] bytes (0 / non-zero).
+ */
+int glr_attn_sup_fwd(const float* attn, const int64_t* attn_off, const int32_t* cap_lens, int img_offset,
+                     const uint8_t* labels, int B, int Hl, int Wl, int ih, int iw, float* loss_b, float* dmap,
+                     void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Row-wise cosine similarity  <x1,x2> / max(|x1|*|x2|, eps)  (gloria/loss/gloria_loss.py:11-16), fp32
+ * [rows, D] inputs.  stats [rows, 3] (dot, |x1|, |x2|) feeds the backward.
+ */
+int glr_cosine_fwd(const float* x1, const float* x2, int rows, int D, float eps, float* out, float* stats,
+                   void* stream);
+int glr_cosine_bwd(const float* x1, const float* x2, const float* stats, const float* g, int rows, int D, float eps,
+                   float* dx1, float* dx2, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
