@@ -81,7 +81,7 @@ struct LaParams {
   // LDS carve (bytes)
   int off_img, off_small;
 #ifdef GLR_STAMPS
-  unsigned long long* stamps;   // diagnostic build only: [grid][8] s_memtime at phase boundaries
+  unsigned long long* stamps;   // diagnostic build only: [grid][12] s_memtime at phase boundaries
 #endif
 };
 
@@ -91,7 +91,7 @@ struct LaParams {
     if (tid == 0 && p.stamps) {                                                             \
       unsigned long long t_;                                                                \
       asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");            \
-      p.stamps[(size_t)blockIdx.x * 8 + (i)] = t_;                                          \
+      p.stamps[(size_t)blockIdx.x * 12 + (i)] = t_;                                          \
     }                                                                                       \
   } while (0)
 #else
@@ -433,26 +433,35 @@ __global__ void __launch_bounds__(NTHR) k_local_attn(LaParams p) {
     // (word-row loop outermost: the per-word scalars are live for one row at a time)
     float zq[16], dq[16];
     if (wactive) {
+      // a lane's 16 word rows increase with q, so their sentence ids form runs: the per-(sentence, region)
+      // log-sum-exp is (re)loaded only when the run changes
+      int cur = -2;
+      float lcur[3] = {0.f, 0.f, 0.f};
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         const int word = wm * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
         const int sg = wseg[word];
-        const int sgc = max(sg, 0);
-        const int sent = seg_sent[sgc];
         float zi = 0.f, be = 0.f, al = 0.f;
         if (BWD) { zi = w_zi[word]; be = w_be[word]; al = w_al[word]; }
+        if (sg != cur && sg >= 0) {
+          cur = sg;
+          const int sent = seg_sent[sg];
+#pragma unroll
+          for (int j = 0; j < 3; ++j) {
+            const int region = min((wg + 4 * j) * 32 + l31, S_pad - 1);
+            if (BWD) lcur[j] = p.lse[((size_t)b * p.n_sent + sent) * S_pad + region];
+            else lcur[j] = (nsub > 1) ? mrun[region] : sc[sg * SCP + region];
+          }
+        }
         float zacc = 0.f, dacc = 0.f;
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
           const int blk = wg + 4 * j;
           if (blk < nrb) {
             const int region = blk * 32 + l31;
-            // branch-free: invalid (empty slot / padded region) elements read a valid dummy and are zeroed
+            // branch-free: invalid (empty slot / padded region) elements are zeroed
             const bool ok = sg >= 0 && region < p.S_eff;
-            float l;
-            if (BWD) l = p.lse[((size_t)b * p.n_sent + sent) * S_pad + region];
-            else l = (nsub > 1) ? mrun[region] : sc[sgc * SCP + region];
-            const float a1 = ok ? __expf(acc[j][q] - l) : 0.f;
+            const float a1 = ok ? __expf(acc[j][q] - lcur[j]) : 0.f;
             const float e2 = ok ? __expf(p.temp1 * a1) : 0.f;
             if (BWD) {
               O::from_f32(img + word * IMP + region * ESZ, be * (e2 * zi));
@@ -574,27 +583,51 @@ __global__ void __launch_bounds__(NTHR) k_local_attn(LaParams p) {
         for (int i = tid; i < nseg * S_pad; i += NTHR) rho[i] = 0.f;
         __syncthreads();
       }
+      GLR_STAMP(5);
+      // rho[r, sentence] += sum over this lane's rows of the sentence of a1*da1: the rows of a sentence
+      // are a run along q, so the sum is kept in registers and ONE LDS atomic is issued per run
+      // (16 same-address atomics per lane serialise in the LDS atomic unit: 76k -> cycles measured)
+      {
+        int cur = -1;
+        float run[3] = {0.f, 0.f, 0.f};
+        const bool do_rho = (nsub == 1 || sweep == 0);
 #pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const int word = wm * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
-        const int sg = wseg[word];
-        const int rrow = (nsub > 1) ? 0 : max(sg, 0);
-        const float zi = w_zi[word], ka = w_ka[word];
+        for (int q = 0; q < 16; ++q) {
+          const int word = wm * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+          const int sg = wseg[word];
+          const int rrow = (nsub > 1) ? 0 : sg;
+          const float zi = w_zi[word], ka = w_ka[word];
+          if (sg >= 0 && rrow != cur) {
+            if (cur >= 0 && do_rho) {
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-          const int blk = wg + 4 * j;
-          if (blk < nrb) {
-            const int region = blk * 32 + l31;
-            const float a1 = a1r[j][q];
-            const bool ok = sg >= 0 && region < p.S_eff;
-            const float a2 = __expf(p.temp1 * a1) * zi;
-            const float da1 = ok ? p.temp1 * a2 * (-acc[j][q] - ka) : 0.f;
-            if (nsub == 1 || sweep == 0) atomicAdd(&rho[rrow * S_pad + region], ok ? a1 * da1 : 0.f);
-            acc[j][q] = da1;
+              for (int j = 0; j < 3; ++j)
+                if (wg + 4 * j < nrb) atomicAdd(&rho[cur * S_pad + (wg + 4 * j) * 32 + l31], run[j]);
+            }
+            cur = rrow;
+            run[0] = run[1] = run[2] = 0.f;
           }
+#pragma unroll
+          for (int j = 0; j < 3; ++j) {
+            const int blk = wg + 4 * j;
+            if (blk < nrb) {
+              const int region = blk * 32 + l31;
+              const float a1 = a1r[j][q];
+              const bool ok = sg >= 0 && region < p.S_eff;
+              const float a2 = __expf(p.temp1 * a1) * zi;
+              const float da1 = ok ? p.temp1 * a2 * (-acc[j][q] - ka) : 0.f;
+              run[j] += ok ? a1 * da1 : 0.f;
+              acc[j][q] = da1;
+            }
+          }
+        }
+        if (cur >= 0 && do_rho) {
+#pragma unroll
+          for (int j = 0; j < 3; ++j)
+            if (wg + 4 * j < nrb) atomicAdd(&rho[cur * S_pad + (wg + 4 * j) * 32 + l31], run[j]);
         }
       }
       __syncthreads();
+      GLR_STAMP(6);
       if (sweep == 1) {
         // outputs X = ds + alpha*a2 and a2, staged through the (now free) image region so that every
         // global store is a 16-byte piece of a full row; rows >= tw of the tile are zero
@@ -626,6 +659,7 @@ __global__ void __launch_bounds__(NTHR) k_local_attn(LaParams p) {
             }
           }
           wg_barrier();
+          GLR_STAMP(7 + 2 * which);
           unsigned char* dst = which == 0 ? p.xout : p.aout;
           for (int i = tid; i < TW * ppr; i += NTHR) {
             const int row = i / ppr, pc = i % ppr;
@@ -636,10 +670,11 @@ __global__ void __launch_bounds__(NTHR) k_local_attn(LaParams p) {
             *reinterpret_cast<uint4*>(dst + grow * rowb + pc * 16) = v;
           }
           wg_barrier();      // LDS reads done; the global stores stay in flight (no vmcnt drain)
+          GLR_STAMP(8 + 2 * which);
         }
       }
     }
-    GLR_STAMP(5);
+    GLR_STAMP(11);
   }  // sub / sweep loops
 }
 

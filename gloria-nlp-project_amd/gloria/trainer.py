@@ -33,6 +33,10 @@ class Trainer:
         opt = model.configure_optimizers()
         self.optimizer, self.scheduler = opt["optimizer"], opt["lr_scheduler"]
         self.params = [p for g in self.optimizer.param_groups for p in g["params"]]
+        self.reducer = None
+        if self.dist is not None and self.dist.active:
+            from .dist import GradReducer
+            self.reducer = GradReducer(self.params, self.dist)      # grads become views of flat buckets
         return model
 
     def to_device(self, batch):
@@ -52,10 +56,13 @@ class Trainer:
         with ctx:
             out = model.training_step(batch, batch_idx)
         loss = out["loss"]
-        self.optimizer.zero_grad(set_to_none=True)
-        loss.backward()
-        if self.dist is not None and self.dist.active:
-            self.dist.allreduce_grads(self.params)
+        if self.reducer is not None:
+            self.reducer.zero_grad()
+            loss.backward()                   # bucket all-reduces start as soon as a bucket is complete
+            self.reducer.finish()
+        else:
+            self.optimizer.zero_grad(set_to_none=True)
+            loss.backward()
         if self.clip:
             torch.nn.utils.clip_grad_norm_(self.params, self.clip)
         self.optimizer.step()

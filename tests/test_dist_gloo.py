@@ -104,8 +104,20 @@ def _worker(rank, port, out):
         p[1].grad = torch.full((3, 2), 10.0 * (rank + 1))
         dctx.allreduce_grads(p, bucket_bytes=16)
         ints = dctx.all_gather_ints([rank, rank + 10])
+        # overlapped bucket reducer: grads are views of flat buckets, hooks fire during backward
+        from gloria.dist import GradReducer
+        torch.manual_seed(0)
+        lin = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Tanh(), torch.nn.Linear(5, 3), torch.nn.Linear(3, 1))
+        unused = torch.nn.Parameter(torch.ones(4))                 # never receives a gradient
+        plist = list(lin.parameters()) + [unused]
+        red = GradReducer(plist, dctx, bucket_bytes=64)
+        red.zero_grad()
+        x = torch.full((2, 6), float(rank + 1))
+        lin(x).sum().backward()
+        red.finish()
+        rgrads = [p.grad.clone() for p in plist]
         torch.save({"loss": loss.detach(), "gi": li.grad, "gw": lw.grad, "gig": lig.grad, "gtg": ltg.grad,
-                    "maps": [m.detach() for m in maps], "p0": p[0].grad, "p1": p[1].grad, "ints": ints},
+                    "maps": [m.detach() for m in maps], "p0": p[0].grad, "p1": p[1].grad, "ints": ints, "rgrads": rgrads},
                    os.path.join(out, f"r{rank}.pt"))
     finally:
         dist.destroy_process_group()
@@ -137,3 +149,15 @@ def test_sharded_loss_equals_full_batch(tmp_path):
             np.testing.assert_allclose(res[r]["maps"][k].numpy(), l[5][r * per + k].detach().numpy(), rtol=1e-5, atol=1e-7)
         assert torch.equal(res[r]["p0"], torch.full((5,), 3.0)) and torch.equal(res[r]["p1"], torch.full((3, 2), 30.0))
         assert res[r]["ints"] == [0, 10, 1, 11]
+    # reducer: every rank ends with the SUM over ranks of the single-process gradients
+    torch.manual_seed(0)
+    lin = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Tanh(), torch.nn.Linear(5, 3), torch.nn.Linear(3, 1))
+    want = [torch.zeros_like(p) for p in lin.parameters()]
+    for r in range(WORLD):
+        lin.zero_grad()
+        lin(torch.full((2, 6), float(r + 1))).sum().backward()
+        want = [w + p.grad for w, p in zip(want, lin.parameters())]
+    for r in range(WORLD):
+        for a, b in zip(res[r]["rgrads"][:-1], want):
+            np.testing.assert_allclose(a.numpy(), b.numpy(), rtol=1e-5, atol=1e-6)
+        assert torch.equal(res[r]["rgrads"][-1], torch.zeros(4))

@@ -18,7 +18,7 @@ lens = sorted((int(x) for x in np.random.default_rng(1).integers(5, 41, size=B))
 L = N.lib()
 L.glr_debug_set_stamps.argtypes = [ctypes.c_void_p]
 grid = 8 * 32 * 100
-buf = torch.zeros(grid * 8, dtype=torch.int64, device=dev)
+buf = torch.zeros(grid * 12, dtype=torch.int64, device=dev)
 def run():
     sim, _, _ = gl.local_similarity(img, words, lens, want_attn=False)
     if bwd:
@@ -26,11 +26,17 @@ def run():
 run(); torch.cuda.synchronize()
 L.glr_debug_set_stamps(ctypes.c_void_p(buf.data_ptr()))
 run(); torch.cuda.synchronize()
-st = buf.cpu().numpy().reshape(grid, 8)
+st = buf.cpu().numpy().reshape(grid, 12)
 st = st[st[:, 0] > 0]
-d = np.diff(st[:, :6].astype(np.float64), axis=1)
-names = ["P1 gemm(T.V^T)", "scores->LDS + walk", "P2 elementwise+image", "P3 gemm(E.G^T)", "P4 epilogue"]
-tot = (st[:, 5] - st[:, 0]).astype(np.float64)
+if bwd:
+    cols = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11]
+    names = ["P1 gemm(T.V^T)", "-", "P2 elementwise+image", "P3 gemm(E.G^T)", "rho zero", "P4 da1 + LDS atomics",
+             "X: compute+stage", "X: copy out", "a2: compute+stage", "a2: copy out", "tail"]
+else:
+    cols = [0, 1, 2, 3, 4, 11]
+    names = ["P1 gemm(T.V^T)", "scores->LDS + walk", "P2 elementwise+image", "P3 gemm(E.G^T)", "P4 epilogue"]
+d = np.diff(st[:, cols].astype(np.float64), axis=1)
+tot = (st[:, 11] - st[:, 0]).astype(np.float64)
 print(f"{'bwd' if bwd else 'fwd'}: workgroups {len(st)}, median cycles per tile {np.median(tot):.0f} (s_memtime ticks)")
 for i, n in enumerate(names):
     print(f"  {n:26s} median {np.median(d[:, i]):9.0f}  share {np.median(d[:, i]) / np.median(tot) * 100:5.1f}%")
