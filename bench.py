@@ -36,7 +36,7 @@ PEAK_BF16_MFMA = 2.5e15        # dense, FLOP/s (MI355X_MICROARCH.md: ~2.5 PF den
 PEAK_F32_MFMA = 157.3e12
 
 
-def build(cfg_batch, precision, device, dist_ctx, bert_layers=12):
+def build(cfg_batch, precision, device, dist_ctx, bert_layers=12, miopen_benchmark=False):
     from gloria import builder
     from gloria.config import pretrain_config
     from gloria.trainer import Trainer
@@ -48,7 +48,7 @@ def build(cfg_batch, precision, device, dist_ctx, bert_layers=12):
     torch.manual_seed(1234)                      # identical initial weights on every rank
     dm = builder.build_data_module(cfg)
     model = builder.build_lightning_model(cfg, dm)
-    trainer = Trainer(cfg, device=device, precision=precision, dist_ctx=dist_ctx)
+    trainer = Trainer(cfg, device=device, precision=precision, dist_ctx=dist_ctx, miopen_benchmark=miopen_benchmark)
     trainer.setup(model)
     model.train()
     return cfg, model, trainer
@@ -98,6 +98,7 @@ def main():
     args = ap.parse_args()
 
     from gloria import dist as gdist
+    from gloria import miopen_db
     from gloria.datasets.synthetic import make_batch
     from gloria.loss import gloria_loss as GL
 
@@ -114,7 +115,8 @@ def main():
     assert GB % world == 0
     per_rank = GB // world
 
-    cfg, model, trainer = build(per_rank, args.precision, device, dctx, args.bert_layers)
+    use_find = miopen_db.activate()           # before the first convolution
+    cfg, model, trainer = build(per_rank, args.precision, device, dctx, args.bert_layers, use_find)
 
     # synthetic global batch, identical on every rank; rank r takes rows r::world (length-balanced)
     full = make_batch(GB, seed=1234, lengths=args.lengths)
@@ -165,7 +167,7 @@ def main():
             "config": {"workload": "imagenome_pretrain_config.yaml: ResNet-50 + BERT-base(12L) + local+global "
                                    "contrastive loss, full training step (fwd+bwd+clip+Adam)",
                        "global_batch": GB, "per_gpu_batch": per_rank, "image": "224x224 -> 299x299",
-                       "tokens": 97, "caption_lengths": args.lengths,
+                       "tokens": 97, "caption_lengths": args.lengths, "miopen_find_db": bool(use_find),
                        "parallelism": f"dp{world}" + (" (text-embedding all-gather + grad all-reduce, RCCL)" if world > 1 else ""),
                        "final_loss": float(loss)},
             "roofline": {"bound": "mfma", "kernel": "k_local_attn_fwd (K1)", "achieved": achieved, "peak": peak,

@@ -115,24 +115,6 @@ template <int N>
 __device__ __forceinline__ void wait_vm() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
-__device__ __forceinline__ void wait_vm_dyn(int n) {   // n is wave-uniform, 0..12
-  switch (n) {
-    case 0: wait_vm<0>(); break;
-    case 1: wait_vm<1>(); break;
-    case 2: wait_vm<2>(); break;
-    case 3: wait_vm<3>(); break;
-    case 4: wait_vm<4>(); break;
-    case 5: wait_vm<5>(); break;
-    case 6: wait_vm<6>(); break;
-    case 7: wait_vm<7>(); break;
-    case 8: wait_vm<8>(); break;
-    case 9: wait_vm<9>(); break;
-    case 10: wait_vm<10>(); break;
-    case 11: wait_vm<11>(); break;
-    case 12: wait_vm<12>(); break;
-    default: wait_vm<0>(); break;
-  }
-}
 __device__ __forceinline__ void wg_barrier() {
   __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): own LDS traffic done (vmcnt untouched)
   __builtin_amdgcn_s_barrier();
@@ -146,70 +128,114 @@ constexpr int PD = 3;       // chunks issued ahead of the one being consumed
 //   A_RES = false: A rows stream from `asrc` (tw rows, pitch apitch bytes) together with B.
 //   A_RES = true : A fragments come from the LDS image `aimg` ([word][k], pitch aimg_pitch bytes).
 // B rows stream from `bsrc` (brows rows, pitch bpitch bytes).  K bytes = nchunk * CHB.
+// NPWC = LDS-DMA pieces every wave issues per chunk (compile time, so every vmcnt wait is an immediate).
+//
 // Ring protocol (NBUF buffers, PD chunks ahead, ONE barrier per chunk): at step c every wave waits
 // for its own DMA pieces of chunk c (counted vmcnt leaves the PD-1 younger chunks in flight),
 // the barrier then publishes chunk c AND proves every wave finished reading chunk c-1, whose
 // buffer is the target of the DMA for chunk c+PD issued right after the barrier.
+// Measured (tools/stamps_k1.py): the streams run at ~27 B/clk/CU of L2->LDS DMA issue, independent of the
+// prefetch depth and of reading fragments one chunk ahead; fewer DMA-issuing waves are slower.
+template <typename O, bool A_RES, int NPWC>
+__device__ __forceinline__ void stream_gemm_n(f32x16 (&acc)[3], unsigned char* ring, int buf_bytes,
+                                              const unsigned char* asrc, size_t apitch,
+                                              const unsigned char* bsrc, size_t bpitch, int brows, int nchunk,
+                                              const unsigned char* aimg, int aimg_pitch, int wave, int lane, int wm,
+                                              int wg, int nrb, int tw) {
+  constexpr int PPR = CHB / 16, RPB = 256 / CHB, KSTEPS = CHB / 32, RPI = 64 / PPR;
+  static_assert(PD == 3, "the wait immediates below assume three chunks ahead");
+  // the per-lane address tables below are loop invariant w.r.t. the caller's tile loops; laundering the
+  // lane id keeps hipcc from hoisting all of them (x8 template instances) to kernel entry, where they
+  // would stay live through every phase and push the kernel into scratch spills
+  asm volatile("" : "+v"(lane));
+  const int l31 = lane & 31, h = lane >> 5;
+  const int arows = A_RES ? 0 : tw;
+  const bool active = wm * 32 < tw;                    // fp32 tiles hold 32 words: odd waves only move data
+  const int winstr = (arows + brows) / RPI;            // 1-KiB DMA pieces per chunk
+  const unsigned ring_lds = lds_addr(ring);
+  const int prow = lane / PPR, pslot = lane % PPR;
+  int koff[KSTEPS];                                    // byte offset of k-step kk inside a swizzled row
+#pragma unroll
+  for (int kk = 0; kk < KSTEPS; ++kk) koff[kk] = ((kk * 2 + h) ^ ((l31 / RPB) & (PPR - 1))) * 16;
+  // every row this lane reads is (multiple of 16) + l31, so its swizzle term depends on l31 only.
+  // Region blocks this wave does not own (small S_pad only) are clamped to a valid row block and their
+  // accumulators are simply never read: NO branches inside the k loop (a guarded load+MFMA pair compiles
+  // to load / wait / MFMA in its own basic block and serialises on the LDS latency)
+  int bofs[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) bofs[j] = (arows + min(wg + 4 * j, nrb - 1) * 32 + l31) * CHB;
+
+  // every wave issues exactly NPWC pieces per chunk (piece indices past the end are clamped to the
+  // last piece: two waves then write the same bytes to the same LDS slot, which is harmless)
+  const unsigned char* psrc[NPWC];
+  unsigned pdst[NPWC];
+#pragma unroll
+  for (int i = 0; i < NPWC; ++i) {
+    const int k = min(wave + 8 * i, winstr - 1);
+    const int row = k * RPI + prow;
+    const int g = pslot ^ ((row / RPB) & (PPR - 1));
+    psrc[i] = ((row < arows) ? (asrc + (size_t)row * apitch) : (bsrc + (size_t)(row - arows) * bpitch)) + g * 16;
+    pdst[i] = ring_lds + k * 1024;
+  }
+  auto issue = [&](int c) {
+    const unsigned boff = (c % NBUF) * buf_bytes;
+#pragma unroll
+    for (int i = 0; i < NPWC; ++i) glds16(psrc[i] + (size_t)c * CHB, pdst[i] + boff);
+  };
+  auto compute = [&](int c) {
+    const unsigned char* rb = ring + (c % NBUF) * buf_bytes;
+    if (active) {
+      const unsigned char* aa0 = A_RES ? (aimg + (wm * 32 + l31) * aimg_pitch + c * CHB + h * 16)
+                                       : (rb + (wm * 32 + l31) * CHB);
+      typename O::frag fa[KSTEPS], fb[KSTEPS][3];
+#pragma unroll
+      for (int kk = 0; kk < KSTEPS; ++kk) {
+        fa[kk] = A_RES ? O::ld(aa0 + kk * 32) : O::ld(aa0 + koff[kk]);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) fb[kk][j] = O::ld(rb + bofs[j] + koff[kk]);
+      }
+      // keep all fragment reads in flight together: without this fence hipcc re-serialises them into
+      // read / wait / MFMA triples
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int kk = 0; kk < KSTEPS; ++kk)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) O::mma(fa[kk], fb[kk][j], acc[j]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
+  for (int c = 0; c < PD && c < nchunk; ++c) issue(c);
+  int c = 0;
+  for (; c + PD <= nchunk; ++c) {                        // steady state: two younger chunks stay in flight
+    wait_vm<2 * NPWC>();
+    wg_barrier();
+    if (c + PD < nchunk) issue(c + PD);
+    compute(c);
+  }
+  for (; c < nchunk; ++c) {                              // tail: nchunk-1-c younger chunks in flight
+    if (nchunk - 1 - c == 1) wait_vm<NPWC>(); else wait_vm<0>();
+    wg_barrier();
+    compute(c);
+  }
+  wg_barrier();                                          // every wave is done with the ring
+}
+
 template <typename O, bool A_RES>
 __device__ __forceinline__ void stream_gemm(f32x16 (&acc)[3], unsigned char* ring, int buf_bytes,
                                             const unsigned char* asrc, size_t apitch,
                                             const unsigned char* bsrc, size_t bpitch, int brows, int nchunk,
                                             const unsigned char* aimg, int aimg_pitch, int wave, int lane, int wm,
                                             int wg, int nrb, int tw) {
-  constexpr int PPR = CHB / 16, RPB = 256 / CHB, KSTEPS = CHB / 32, RPI = 64 / PPR;
-  constexpr int NPW = ((GLR_MAX_SPAD + TW) / RPI + 7) / 8;   // DMA pieces per wave and chunk (upper bound)
-  const int l31 = lane & 31, h = lane >> 5;
-  const int arows = A_RES ? 0 : tw;
-  const bool active = wm * 32 < tw;                    // fp32 tiles hold 32 words: odd waves only move data
-  const int winstr = (arows + brows) / RPI;            // 1-KiB DMA pieces per chunk
-  const int nw = (winstr - wave + 7) / 8;              // pieces this wave issues per chunk
-  const unsigned ring_lds = lds_addr(ring);
-  const int prow = lane / PPR, pslot = lane % PPR;
-  int koff[KSTEPS];                                    // byte offset of k-step kk inside a swizzled row
-#pragma unroll
-  for (int kk = 0; kk < KSTEPS; ++kk) koff[kk] = ((kk * 2 + h) ^ ((l31 / RPB) & (PPR - 1))) * 16;
-
-  auto issue = [&](int c) {
-    const int buf = c % NBUF;
-#pragma unroll
-    for (int i = 0; i < NPW; ++i) {
-      const int k = wave + 8 * i;
-      if (k < winstr) {
-        const int row = k * RPI + prow;
-        const int g = pslot ^ ((row / RPB) & (PPR - 1));
-        const unsigned char* src = (row < arows) ? (asrc + (size_t)row * apitch)
-                                                 : (bsrc + (size_t)(row - arows) * bpitch);
-        glds16(src + (size_t)c * CHB + g * 16, ring_lds + buf * buf_bytes + k * 1024);
-      }
-    }
-  };
-
-  for (int c = 0; c < PD && c < nchunk; ++c) issue(c);
-  for (int c = 0; c < nchunk; ++c) {
-    wait_vm_dyn(min(nchunk - 1 - c, PD - 1) * nw);       // chunk c landed; younger chunks stay in flight
-    wg_barrier();
-    if (c + PD < nchunk) issue(c + PD);
-    const unsigned char* rb = ring + (c % NBUF) * buf_bytes;
-    if (active) {
-      // every row this lane reads is (multiple of 16) + l31, so its swizzle term depends on l31 only;
-      // fragment addresses are one lane base + koff[kk] + an immediate row-block offset
-      const unsigned char* bb0 = rb + (arows + wg * 32 + l31) * CHB;
-      const unsigned char* aa0 = A_RES ? (aimg + (wm * 32 + l31) * aimg_pitch + c * CHB + h * 16)
-                                       : (rb + (wm * 32 + l31) * CHB);
-#pragma unroll
-      for (int kk = 0; kk < KSTEPS; ++kk) {
-        const typename O::frag a = A_RES ? O::ld(aa0 + kk * 32) : O::ld(aa0 + koff[kk]);
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-          if (wg + 4 * j < nrb) {
-            const typename O::frag bb = O::ld(bb0 + koff[kk] + j * (4 * 32 * CHB));
-            O::mma(a, bb, acc[j]);
-          }
-        }
-      }
-    }
+  constexpr int RPI = 64 / (CHB / 16);
+  const int winstr = ((A_RES ? 0 : tw) + brows) / RPI;
+  const int npw = (winstr + 7) / 8;                      // workgroup-uniform
+  switch (npw) {
+    case 1: stream_gemm_n<O, A_RES, 1>(acc, ring, buf_bytes, asrc, apitch, bsrc, bpitch, brows, nchunk, aimg, aimg_pitch, wave, lane, wm, wg, nrb, tw); break;
+    case 2: stream_gemm_n<O, A_RES, 2>(acc, ring, buf_bytes, asrc, apitch, bsrc, bpitch, brows, nchunk, aimg, aimg_pitch, wave, lane, wm, wg, nrb, tw); break;
+    case 3: stream_gemm_n<O, A_RES, 3>(acc, ring, buf_bytes, asrc, apitch, bsrc, bpitch, brows, nchunk, aimg, aimg_pitch, wave, lane, wm, wg, nrb, tw); break;
+    default: stream_gemm_n<O, A_RES, 4>(acc, ring, buf_bytes, asrc, apitch, bsrc, bpitch, brows, nchunk, aimg, aimg_pitch, wave, lane, wm, wg, nrb, tw); break;
   }
-  wg_barrier();                                          // every wave is done with the ring
 }
 
 // ---- cross-lane sums without LDS traffic: DPP row_shr adds; lane 15 of every 16-lane row ends

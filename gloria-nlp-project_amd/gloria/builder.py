@@ -65,8 +65,9 @@ def build_optimizer(cfg, lr, model):
     if cfg.train.optimizer.name == "SGD":
         return torch.optim.SGD(params, lr=lr, momentum=cfg.momentum, weight_decay=cfg.weight_decay)
     elif cfg.train.optimizer.name == "Adam":
+        fused = bool(params) and all(p.is_cuda for p in params)      # one multi-tensor launch chain on the GPU
         return torch.optim.Adam(params, lr=lr, weight_decay=float(cfg.train.optimizer.weight_decay),
-                                betas=(0.5, 0.999))
+                                betas=(0.5, 0.999), fused=fused)
     elif cfg.train.optimizer.name == "AdamW":
         return torch.optim.AdamW(params, lr=lr, weight_decay=float(cfg.train.optimizer.weight_decay))
 
