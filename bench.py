@@ -115,7 +115,7 @@ def main():
     assert GB % world == 0
     per_rank = GB // world
 
-    use_find = miopen_db.activate()           # before the first convolution
+    use_find = miopen_db.activate(per_rank)   # before the first convolution
     cfg, model, trainer = build(per_rank, args.precision, device, dctx, args.bert_layers, use_find)
 
     # synthetic global batch, identical on every rank; rank r takes rows r::world (length-balanced)

@@ -59,6 +59,8 @@ struct LaParams {
   const int* tile_first;
   const int* order;
   const int* tile_nsub;
+  const int* item_tile;         // first tiles of the work items of this launch (single tiles or pairs)
+  int n_items;
   int n_tiles, n_sent, n_slots, B_img, D, S_eff, S_pad;
   int tw;                       // populated word slots per tile: 64 (bf16) or 32 (fp32, LDS budget)
   float temp1, temp2, temp3;
@@ -136,20 +138,22 @@ constexpr int PD = 3;       // chunks issued ahead of the one being consumed
 // buffer is the target of the DMA for chunk c+PD issued right after the barrier.
 // Measured (tools/stamps_k1.py): the streams run at ~27 B/clk/CU of L2->LDS DMA issue, independent of the
 // prefetch depth and of reading fragments one chunk ahead; fewer DMA-issuing waves are slower.
-template <typename O, bool A_RES, int NPWC>
-__device__ __forceinline__ void stream_gemm_n(f32x16 (&acc)[3], unsigned char* ring, int buf_bytes,
+template <typename O, bool A_RES, int NPWC, int NH = 1, int NB = NBUF>
+__device__ __forceinline__ void stream_gemm_n(f32x16 (&acc)[3], f32x16 (&acc2)[3], int img2_off, unsigned char* ring,
+                                              int buf_bytes,
                                               const unsigned char* asrc, size_t apitch,
                                               const unsigned char* bsrc, size_t bpitch, int brows, int nchunk,
                                               const unsigned char* aimg, int aimg_pitch, int wave, int lane, int wm,
                                               int wg, int nrb, int tw) {
   constexpr int PPR = CHB / 16, RPB = 256 / CHB, KSTEPS = CHB / 32, RPI = 64 / PPR;
-  static_assert(PD == 3, "the wait immediates below assume three chunks ahead");
+  constexpr int PDD = NB - 1;                          // chunks issued ahead; buffer (c+PDD) % NB == (c-1) % NB
+  static_assert(PDD == 1 || PDD == 3, "wait immediates are written for 2- and 4-deep rings");
   // the per-lane address tables below are loop invariant w.r.t. the caller's tile loops; laundering the
   // lane id keeps hipcc from hoisting all of them (x8 template instances) to kernel entry, where they
   // would stay live through every phase and push the kernel into scratch spills
   asm volatile("" : "+v"(lane));
   const int l31 = lane & 31, h = lane >> 5;
-  const int arows = A_RES ? 0 : tw;
+  const int arows = A_RES ? 0 : NH * tw;               // NH tiles of tw populated rows (one tile = TW slots)
   const bool active = wm * 32 < tw;                    // fp32 tiles hold 32 words: odd waves only move data
   const int winstr = (arows + brows) / RPI;            // 1-KiB DMA pieces per chunk
   const unsigned ring_lds = lds_addr(ring);
@@ -174,23 +178,26 @@ __device__ __forceinline__ void stream_gemm_n(f32x16 (&acc)[3], unsigned char* r
     const int k = min(wave + 8 * i, winstr - 1);
     const int row = k * RPI + prow;
     const int g = pslot ^ ((row / RPB) & (PPR - 1));
-    psrc[i] = ((row < arows) ? (asrc + (size_t)row * apitch) : (bsrc + (size_t)(row - arows) * bpitch)) + g * 16;
+    // A row r of the ring = populated row (r % tw) of tile (r / tw)
+    psrc[i] = ((row < arows) ? (asrc + ((size_t)(row / tw) * TW + (row % tw)) * apitch)
+                             : (bsrc + (size_t)(row - arows) * bpitch)) + g * 16;
     pdst[i] = ring_lds + k * 1024;
   }
   auto issue = [&](int c) {
-    const unsigned boff = (c % NBUF) * buf_bytes;
+    const unsigned boff = (c % NB) * buf_bytes;
 #pragma unroll
     for (int i = 0; i < NPWC; ++i) glds16(psrc[i] + (size_t)c * CHB, pdst[i] + boff);
   };
   auto compute = [&](int c) {
-    const unsigned char* rb = ring + (c % NBUF) * buf_bytes;
+    const unsigned char* rb = ring + (c % NB) * buf_bytes;
     if (active) {
       const unsigned char* aa0 = A_RES ? (aimg + (wm * 32 + l31) * aimg_pitch + c * CHB + h * 16)
                                        : (rb + (wm * 32 + l31) * CHB);
-      typename O::frag fa[KSTEPS], fb[KSTEPS][3];
+      typename O::frag fa[KSTEPS], fa2[KSTEPS], fb[KSTEPS][3];
 #pragma unroll
       for (int kk = 0; kk < KSTEPS; ++kk) {
         fa[kk] = A_RES ? O::ld(aa0 + kk * 32) : O::ld(aa0 + koff[kk]);
+        if (NH == 2) fa2[kk] = A_RES ? O::ld(aa0 + img2_off + kk * 32) : O::ld(aa0 + tw * CHB + koff[kk]);
 #pragma unroll
         for (int j = 0; j < 3; ++j) fb[kk][j] = O::ld(rb + bofs[j] + koff[kk]);
       }
@@ -200,20 +207,23 @@ __device__ __forceinline__ void stream_gemm_n(f32x16 (&acc)[3], unsigned char* r
 #pragma unroll
       for (int kk = 0; kk < KSTEPS; ++kk)
 #pragma unroll
-        for (int j = 0; j < 3; ++j) O::mma(fa[kk], fb[kk][j], acc[j]);
+        for (int j = 0; j < 3; ++j) {
+          O::mma(fa[kk], fb[kk][j], acc[j]);
+          if (NH == 2) O::mma(fa2[kk], fb[kk][j], acc2[j]);
+        }
       __builtin_amdgcn_sched_barrier(0);
     }
   };
 
-  for (int c = 0; c < PD && c < nchunk; ++c) issue(c);
+  for (int c = 0; c < PDD && c < nchunk; ++c) issue(c);
   int c = 0;
-  for (; c + PD <= nchunk; ++c) {                        // steady state: two younger chunks stay in flight
-    wait_vm<2 * NPWC>();
+  for (; c + PDD <= nchunk; ++c) {                       // steady state: PDD-1 younger chunks stay in flight
+    wait_vm<(PDD - 1) * NPWC>();
     wg_barrier();
-    if (c + PD < nchunk) issue(c + PD);
+    if (c + PDD < nchunk) issue(c + PDD);
     compute(c);
   }
-  for (; c < nchunk; ++c) {                              // tail: nchunk-1-c younger chunks in flight
+  for (; c < nchunk; ++c) {                              // tail (PDD == 3 only): nchunk-1-c younger chunks in flight
     if (nchunk - 1 - c == 1) wait_vm<NPWC>(); else wait_vm<0>();
     wg_barrier();
     compute(c);
@@ -221,21 +231,24 @@ __device__ __forceinline__ void stream_gemm_n(f32x16 (&acc)[3], unsigned char* r
   wg_barrier();                                          // every wave is done with the ring
 }
 
-template <typename O, bool A_RES>
-__device__ __forceinline__ void stream_gemm(f32x16 (&acc)[3], unsigned char* ring, int buf_bytes,
-                                            const unsigned char* asrc, size_t apitch,
+template <typename O, bool A_RES, int NH = 1, int NB = NBUF>
+__device__ __forceinline__ void stream_gemm(f32x16 (&acc)[3], f32x16 (&acc2)[3], int img2_off, unsigned char* ring,
+                                            int buf_bytes, const unsigned char* asrc, size_t apitch,
                                             const unsigned char* bsrc, size_t bpitch, int brows, int nchunk,
                                             const unsigned char* aimg, int aimg_pitch, int wave, int lane, int wm,
                                             int wg, int nrb, int tw) {
   constexpr int RPI = 64 / (CHB / 16);
-  const int winstr = ((A_RES ? 0 : tw) + brows) / RPI;
+  const int winstr = ((A_RES ? 0 : NH * tw) + brows) / RPI;
   const int npw = (winstr + 7) / 8;                      // workgroup-uniform
+#define GLR_SG(N) stream_gemm_n<O, A_RES, N, NH, NB>(acc, acc2, img2_off, ring, buf_bytes, asrc, apitch, bsrc, bpitch, brows, \
+                                                 nchunk, aimg, aimg_pitch, wave, lane, wm, wg, nrb, tw)
   switch (npw) {
-    case 1: stream_gemm_n<O, A_RES, 1>(acc, ring, buf_bytes, asrc, apitch, bsrc, bpitch, brows, nchunk, aimg, aimg_pitch, wave, lane, wm, wg, nrb, tw); break;
-    case 2: stream_gemm_n<O, A_RES, 2>(acc, ring, buf_bytes, asrc, apitch, bsrc, bpitch, brows, nchunk, aimg, aimg_pitch, wave, lane, wm, wg, nrb, tw); break;
-    case 3: stream_gemm_n<O, A_RES, 3>(acc, ring, buf_bytes, asrc, apitch, bsrc, bpitch, brows, nchunk, aimg, aimg_pitch, wave, lane, wm, wg, nrb, tw); break;
-    default: stream_gemm_n<O, A_RES, 4>(acc, ring, buf_bytes, asrc, apitch, bsrc, bpitch, brows, nchunk, aimg, aimg_pitch, wave, lane, wm, wg, nrb, tw); break;
+    case 1: GLR_SG(1); break;
+    case 2: GLR_SG(2); break;
+    case 3: GLR_SG(3); break;
+    default: GLR_SG(4); break;
   }
+#undef GLR_SG
 }
 
 // ---- cross-lane sums without LDS traffic: DPP row_shr adds; lane 15 of every 16-lane row ends
@@ -271,9 +284,9 @@ __global__ void __launch_bounds__(NTHR) k_local_attn(LaParams p) {
     tile0 = p.sent_slot0[p.img_offset + b] / TW;
   } else {
     const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
-    b = (q / p.n_tiles) * 8 + xcd;
-    tile0 = q % p.n_tiles;
+    b = (q / p.n_items) * 8 + xcd;
     if (b >= p.B_img) return;
+    tile0 = p.item_tile[q % p.n_items];
   }
   int nsub = p.tile_nsub[tile0];      // 0: ordinary tile, k > 1: head of a k-tile sentence, < 0: continuation
   if (nsub < 0) return;
@@ -390,7 +403,7 @@ __global__ void __launch_bounds__(NTHR) k_local_attn(LaParams p) {
     for (int j = 0; j < 3; ++j)
 #pragma unroll
       for (int q = 0; q < 16; ++q) acc[j][q] = 0.f;
-    stream_gemm<O, false>(acc, ring, buf1, p.tp + (size_t)tile * TW * rowbytes1, rowbytes1, vt_b, rowbytes1, S_pad,
+    stream_gemm<O, false>(acc, acc, 0, ring, buf1, p.tp + (size_t)tile * TW * rowbytes1, rowbytes1, vt_b, rowbytes1, S_pad,
                           nch1, nullptr, 0, wave, lane, wm, wg, nrb, tw);
 
     GLR_STAMP(1);
@@ -523,7 +536,7 @@ __global__ void __launch_bounds__(NTHR) k_local_attn(LaParams p) {
 
     GLR_STAMP(3);
     // ================= P3: acc[w, r] (+)= image . G^T =================
-    stream_gemm<O, true>(acc, ring, buf2, nullptr, 0, gram_b, rowbytes2, S_pad, nch2, img, IMP, wave, lane, wm, wg,
+    stream_gemm<O, true>(acc, acc, 0, ring, buf2, nullptr, 0, gram_b, rowbytes2, S_pad, nch2, img, IMP, wave, lane, wm, wg,
                          nrb, tw);
 
     GLR_STAMP(4);
@@ -704,6 +717,255 @@ __global__ void __launch_bounds__(NTHR) k_local_attn(LaParams p) {
   }  // sub / sweep loops
 }
 
+// ------------------------------------------------------------------------------------------
+// Forward for a PAIR of ordinary tiles (128 words) of one image: vt[b] AND gram[b] are streamed once
+// for both tiles (the streams are L2->LDS bandwidth bound, ~27 B/clk/CU, so bytes per word decide the
+// time).  Both tiles' scores live in registers (2 x 48 fp32) through the statistics walks and P2;
+// LDS:  [0, 2*IMG)      images of tile A and B        | aliased earlier by the P1 ring / score tile
+//       [2*IMG, +TAB)   lse tables [2][16][S_pad]     | aliased later by the 2-deep P3 ring
+//       small           segment tables, reductions
+// Tiles with more than PAIR_MAXSEG sentences are not paired by the planner.
+constexpr int PAIR_MAXSEG = 16;
+
+template <typename O>
+__global__ void __launch_bounds__(NTHR) k_local_attn_pair(LaParams p) {
+  constexpr int ESZ = O::ESZ, CB = CHB;
+  constexpr int SCP = GLR_MAX_SPAD;
+  constexpr int IMP = GLR_MAX_SPAD * ESZ + 16;
+  constexpr int IMG = TW * IMP;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave & 1, wg = wave >> 1;
+  const int l31 = lane & 31, h = lane >> 5;
+
+  const int xcd = blockIdx.x & 7, qq = blockIdx.x >> 3;
+  const int b = (qq / p.n_items) * 8 + xcd;
+  if (b >= p.B_img) return;
+  const int tile0 = p.item_tile[qq % p.n_items];
+
+  const int S_pad = p.S_pad, D = p.D;
+  const int nrb = S_pad >> 5;
+  const int tw = p.tw;
+
+  unsigned char* ring = smem;
+  float* sc = reinterpret_cast<float*>(smem);
+  unsigned char* img0 = smem;
+  float* tab = reinterpret_cast<float*>(smem + p.off_img);       // [2][PAIR_MAXSEG][S_pad]
+  unsigned char* ring3 = smem + p.off_img;
+  int* seg_w0 = reinterpret_cast<int*>(smem + p.off_small);      // [2][TW] each
+  int* seg_n = seg_w0 + 2 * TW;
+  int* seg_sent = seg_n + 2 * TW;
+  int* wseg = seg_sent + 2 * TW;
+  float* red = reinterpret_cast<float*>(wseg + 2 * TW);          // [2][8][TW]
+  float* zsum = red + 16 * TW;                                   // [2][TW]
+  float* dsum = zsum + 2 * TW;                                   // [2][TW]
+  float* exs = dsum + 2 * TW;                                    // [TW]
+  int* diag = reinterpret_cast<int*>(exs + TW);                  // [2][2]
+  int* nsegs = diag + 4;                                         // [2]
+
+  const size_t rowbytes1 = (size_t)D * ESZ, rowbytes2 = (size_t)S_pad * ESZ;
+  const unsigned char* vt_b = p.vt + (size_t)b * S_pad * rowbytes1;
+  const unsigned char* gram_b = p.gram + (size_t)b * S_pad * rowbytes2;
+
+  // ---- segment tables of both tiles
+  if (tid < 2 * TW) wseg[tid] = -1;
+  if (tid < 4) diag[tid] = 0;
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int tile = tile0 + t;
+    const int sf = p.tile_first[tile], ns = p.tile_first[tile + 1] - sf;
+    if (tid == 0) nsegs[t] = ns;
+    if (tid < ns) {
+      const int sent = p.order[sf + tid];
+      seg_sent[t * TW + tid] = sent;
+      seg_w0[t * TW + tid] = p.sent_slot0[sent] - tile * TW;
+      seg_n[t * TW + tid] = p.cap_lens[sent];
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    if (tid < nsegs[t]) {
+      const int w0 = seg_w0[t * TW + tid], n = seg_n[t * TW + tid];
+      for (int w = 0; w < n; ++w) wseg[t * TW + w0 + w] = tid;
+      if (seg_sent[t * TW + tid] == p.img_offset + b) { diag[2 * t] = w0; diag[2 * t + 1] = n; }
+    }
+  }
+
+  // ================= P1 (both tiles, one stream of vt[b]) =================
+  f32x16 accA[3], accB[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) { accA[j][q] = 0.f; accB[j][q] = 0.f; }
+  __syncthreads();
+  stream_gemm<O, false, 2>(accA, accB, 0, ring, (2 * tw + S_pad) * CB, p.tp + (size_t)tile0 * TW * rowbytes1, rowbytes1,
+                           vt_b, rowbytes1, S_pad, (int)(rowbytes1 / CB), nullptr, 0, wave, lane, wm, wg, nrb, tw);
+
+  // ================= statistics walks: lse[r, sentence] of tile t into tab[t] =================
+  auto walk = [&](f32x16 (&acc)[3], int t) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int blk = wg + 4 * j;
+      if (blk < nrb) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int word = wm * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+          sc[word * SCP + blk * 32 + l31] = acc[j][q];
+        }
+      }
+    }
+    __syncthreads();
+    if (tid < S_pad) {
+      const int r = tid, ns = nsegs[t];
+      for (int s2 = 0; s2 < ns; ++s2) {
+        const int w0 = seg_w0[t * TW + s2], n = seg_n[t * TW + s2];
+        const float* col = sc + w0 * SCP + r;
+        float m = -INFINITY;
+        int w = 0;
+        for (; w + 4 <= n; w += 4) {
+          const float x0 = col[w * SCP], x1 = col[(w + 1) * SCP], x2 = col[(w + 2) * SCP], x3 = col[(w + 3) * SCP];
+          m = fmaxf(m, fmaxf(fmaxf(x0, x1), fmaxf(x2, x3)));
+        }
+        for (; w < n; ++w) m = fmaxf(m, col[w * SCP]);
+        float sum = 0.f;
+        for (w = 0; w + 4 <= n; w += 4) {
+          const float x0 = col[w * SCP], x1 = col[(w + 1) * SCP], x2 = col[(w + 2) * SCP], x3 = col[(w + 3) * SCP];
+          sum += (__expf(x0 - m) + __expf(x1 - m)) + (__expf(x2 - m) + __expf(x3 - m));
+        }
+        for (; w < n; ++w) sum += __expf(col[w * SCP] - m);
+        const float l = m + __logf(sum);
+        tab[(t * PAIR_MAXSEG + s2) * S_pad + r] = l;
+        if (p.lse) p.lse[((size_t)b * p.n_sent + seg_sent[t * TW + s2]) * S_pad + r] = l;
+      }
+    }
+    __syncthreads();
+  };
+  walk(accA, 0);
+  walk(accB, 1);
+
+  // ================= P2: a1, e2 from the scores in registers; LDS images; per-word Z and dot~ =================
+  auto p2 = [&](f32x16 (&acc)[3], int t) {
+    unsigned char* img = img0 + t * IMG;
+    const int rslot = wg * 2 + ((lane >> 4) & 1);
+    int cur = -2;
+    float lcur[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int word = wm * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+      const int sg = wseg[t * TW + word];
+      if (sg != cur && sg >= 0) {
+        cur = sg;
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+          lcur[j] = tab[(t * PAIR_MAXSEG + sg) * S_pad + min((wg + 4 * j) * 32 + l31, S_pad - 1)];
+      }
+      float zacc = 0.f, dacc = 0.f;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const int blk = wg + 4 * j;
+        if (blk < nrb) {
+          const int region = blk * 32 + l31;
+          const bool ok = sg >= 0 && region < p.S_eff;
+          const float a1 = ok ? __expf(acc[j][q] - lcur[j]) : 0.f;
+          const float e2 = ok ? __expf(p.temp1 * a1) : 0.f;
+          O::from_f32(img + word * IMP + region * ESZ, e2);
+          const float e2r = ESZ == 4 ? e2 : bf2f(f2bf(e2));
+          zacc += e2r;
+          dacc += e2r * acc[j][q];
+          acc[j][q] = 0.f;
+        }
+      }
+      const float z = row_sum16(zacc), d = row_sum16(dacc);
+      if ((lane & 15) == 15) {
+        red[(0 * 8 + rslot) * TW + word] = z;
+        red[(1 * 8 + rslot) * TW + word] = d;
+      }
+    }
+    __syncthreads();
+    if (tid < TW) {
+      float z = 0.f, d = 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { z += red[k * TW + tid]; d += red[(8 + k) * TW + tid]; }
+      zsum[t * TW + tid] = z;
+      dsum[t * TW + tid] = d;
+    }
+    __syncthreads();
+  };
+  // NB: the images alias the score tile and the tail of the P1 ring, both dead now; the lse tables live
+  // above the images until P2 of both tiles is done
+  p2(accA, 0);
+  p2(accB, 1);
+
+  // ================= P3 (both tiles, one stream of gram[b]); 2-deep ring over the dead lse tables =================
+  stream_gemm<O, true, 2, 2>(accA, accB, IMG, ring3, S_pad * CB, nullptr, 0, gram_b, rowbytes2, S_pad,
+                            (int)(rowbytes2 / CB), img0, IMP, wave, lane, wm, wg, nrb, tw);
+
+  // ================= P4: |c|^2, cosine, per-sentence aggregate, diagonal attention maps =================
+  auto p4 = [&](f32x16 (&acc)[3], int t) {
+    const int tile = tile0 + t;
+    const unsigned char* img = img0 + t * IMG;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int word = wm * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+      float v = 0.f;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const int blk = wg + 4 * j;
+        if (blk < nrb) v += O::to_f32(img + word * IMP + (blk * 32 + l31) * ESZ) * acc[j][q];
+      }
+      v = row_sum16(v);
+      if ((lane & 15) == 15) red[(wg * 2 + ((lane >> 4) & 1)) * TW + word] = v;
+    }
+    __syncthreads();
+    if (tid < TW) {
+      float nn = 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) nn += red[k * TW + tid];
+      const float z = zsum[t * TW + tid], dd = dsum[t * TW + tid];
+      float cosv = 0.f, nc2 = 0.f;
+      if (z > 0.f) {
+        const float iz = 1.f / z;
+        nc2 = fmaxf(nn, 0.f) * iz * iz;
+        const float den = fmaxf(p.tnorm[(size_t)tile * TW + tid] * sqrtf(nc2), p.eps);
+        cosv = dd * iz / den;
+      }
+      exs[tid] = __expf(p.temp2 * cosv);
+      if (p.wstat) {
+        float* ws = p.wstat + ((size_t)b * p.n_slots + (size_t)tile * TW + tid) * WSTAT;
+        ws[0] = z; ws[1] = cosv; ws[2] = nc2; ws[3] = 0.f;
+      }
+    }
+    __syncthreads();
+    if (tid < nsegs[t]) {
+      const int w0 = seg_w0[t * TW + tid], n = seg_n[t * TW + tid];
+      float v = 0.f;
+      if (p.agg == GLR_AGG_MAX) {
+        for (int w = 0; w < n; ++w) v = fmaxf(v, exs[w0 + w]);
+      } else {
+        for (int w = 0; w < n; ++w) v += exs[w0 + w];
+      }
+      if (p.agg == GLR_AGG_MEAN) v /= (float)n;
+      p.sim[(size_t)b * p.ld_sim + seg_sent[t * TW + tid]] = p.temp3 * __logf(v);
+    }
+    const int dw0 = diag[2 * t], dn = diag[2 * t + 1];
+    if (p.attn != nullptr && dn > 0) {
+      const int sout = p.S_eff - p.strip;
+      float* out = p.attn + p.attn_off[p.img_offset + b];
+      for (int idx = tid; idx < dn * sout; idx += NTHR) {
+        const int w = idx / sout, r = idx % sout + p.strip;
+        out[idx] = O::to_f32(img + (dw0 + w) * IMP + r * ESZ) / zsum[t * TW + dw0 + w];
+      }
+    }
+    __syncthreads();
+  };
+  p4(accA, 0);
+  p4(accB, 1);
+}
+
 #ifdef GLR_STAMPS
 unsigned long long* g_stamps = nullptr;
 #endif
@@ -719,11 +981,24 @@ int carve(LaParams& p, int op_dtype, int S_pad) {
   return p.off_small + 12288;
 }
 
+// pair kernel: [0, 2*IMG) images | [2*IMG, +max(tables, 2-deep P3 ring)) | small
+int carve_pair(LaParams& p, int op_dtype, int S_pad) {
+  const int esz = op_dtype == GLR_F32 ? 4 : 2;
+  const int img_bytes = TW * (GLR_MAX_SPAD * esz + 16);
+  const int tab_bytes = 2 * PAIR_MAXSEG * S_pad * 4;
+  const int ring3 = 2 * S_pad * CHB;
+  const int ring1 = NBUF * (2 * p.tw + S_pad) * CHB;
+  p.off_img = 2 * img_bytes;                       // tables / P3 ring
+  p.off_small = max(p.off_img + max(tab_bytes, ring3), ring1);
+  return p.off_small + 10240;
+}
+
 template <bool BWD>
 int launch(LaParams& p, int op_dtype, void* stream) {
   const int lds = carve(p, op_dtype, p.S_pad);
   if (lds > 160 * 1024) return GLR_EINVAL;
-  const int grid = p.pair_only ? p.B_img : ((p.B_img + 7) / 8) * 8 * p.n_tiles;
+  const int grid = p.pair_only ? p.B_img : ((p.B_img + 7) / 8) * 8 * p.n_items;
+  if (grid <= 0) return GLR_OK;
   hipStream_t st = (hipStream_t)stream;
   if (op_dtype == GLR_BF16) {
     if (hipFuncSetAttribute((const void*)k_local_attn<OpBF16, BWD>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return GLR_ELAUNCH;
@@ -732,6 +1007,17 @@ int launch(LaParams& p, int op_dtype, void* stream) {
     if (hipFuncSetAttribute((const void*)k_local_attn<OpF32, BWD>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return GLR_ELAUNCH;
     hipLaunchKernelGGL((k_local_attn<OpF32, BWD>), dim3(grid), dim3(NTHR), lds, st, p);
   }
+  GLR_CHECK_LAUNCH();
+  return GLR_OK;
+}
+
+int launch_pair(LaParams& p, int op_dtype, void* stream) {
+  if (op_dtype != GLR_BF16) return GLR_EINVAL;      // the fp32 mode (32-word tiles) is never paired
+  const int lds = carve_pair(p, op_dtype, p.S_pad);
+  if (lds > 160 * 1024) return GLR_EINVAL;
+  const int grid = ((p.B_img + 7) / 8) * 8 * p.n_items;
+  if (hipFuncSetAttribute((const void*)k_local_attn_pair<OpBF16>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return GLR_ELAUNCH;
+  hipLaunchKernelGGL((k_local_attn_pair<OpBF16>), dim3(grid), dim3(NTHR), lds, (hipStream_t)stream, p);
   GLR_CHECK_LAUNCH();
   return GLR_OK;
 }
@@ -748,7 +1034,8 @@ int fill_common(LaParams& p, const void* vt, const void* gram, const void* tp, c
   if (agg < 0 || agg > 2) return GLR_EINVAL;
   p.vt = (const unsigned char*)vt; p.gram = (const unsigned char*)gram; p.tp = (const unsigned char*)tp;
   p.tnorm = tnorm; p.sent_slot0 = sent_slot0; p.cap_lens = cap_lens; p.tile_first = tile_first; p.order = order;
-  p.tile_nsub = tile_nsub; p.n_tiles = n_tiles; p.n_sent = n_sent; p.n_slots = n_tiles * TW; p.B_img = B_img;
+  p.tile_nsub = tile_nsub; p.item_tile = nullptr; p.n_items = 0; p.n_tiles = n_tiles; p.n_sent = n_sent;
+  p.n_slots = n_tiles * TW; p.B_img = B_img;
   p.D = D; p.S_eff = S_eff; p.S_pad = S_pad; p.temp1 = temp1; p.temp2 = temp2; p.temp3 = temp3; p.agg = agg;
   p.eps = eps;
   p.tw = glr_tile_capacity(op_dtype);
@@ -763,46 +1050,57 @@ int fill_common(LaParams& p, const void* vt, const void* gram, const void* tp, c
 
 }  // namespace
 
-
-
 extern "C" int glr_local_attn_fwd(const void* vt, const void* gram, const void* tp, const float* tnorm,
                                   const int32_t* sent_slot0, const int32_t* cap_lens,
                                   const int32_t* tile_first, const int32_t* order, const int32_t* tile_nsub,
+                                  const int32_t* single_tile, int n_single, const int32_t* pair_tile, int n_pair,
                                   int n_tiles, int n_sent, int B_img, int D, int S_eff, float temp1, float temp2,
                                   float temp3, int agg, float eps, float* sim, int ld_sim, float* lse, float* wstat,
                                   float* attn, const int64_t* attn_off, int strip, int pair_only, int img_offset,
                                   int op_dtype, void* stream) {
   LaParams p;
-  const int rc = fill_common(p, vt, gram, tp, tnorm, sent_slot0, cap_lens, tile_first, order, tile_nsub, n_tiles,
-                             n_sent, B_img, D, S_eff, temp1, temp2, temp3, agg, eps, op_dtype);
+  int rc = fill_common(p, vt, gram, tp, tnorm, sent_slot0, cap_lens, tile_first, order, tile_nsub, n_tiles,
+                       n_sent, B_img, D, S_eff, temp1, temp2, temp3, agg, eps, op_dtype);
   if (rc != GLR_OK) return rc;
   if (!sim || (attn && !attn_off)) return GLR_EINVAL;
+  if (n_single < 0 || n_pair < 0 || (n_single > 0 && !single_tile) || (n_pair > 0 && !pair_tile)) return GLR_EINVAL;
   if (pair_only && img_offset + B_img > n_sent) return GLR_EINVAL;
+  if (!pair_only && n_single + n_pair == 0) return GLR_EINVAL;
   p.sim = sim; p.ld_sim = ld_sim; p.lse = lse; p.wstat = wstat; p.attn = attn;
   p.attn_off = (const long long*)attn_off; p.strip = strip; p.pair_only = pair_only; p.img_offset = img_offset;
-  return launch<false>(p, op_dtype, stream);
+  if (pair_only || n_single > 0) {
+    p.item_tile = single_tile; p.n_items = n_single;
+    rc = launch<false>(p, op_dtype, stream);
+    if (rc != GLR_OK) return rc;
+  }
+  if (!pair_only && n_pair > 0) {
+    p.item_tile = pair_tile; p.n_items = n_pair;
+    rc = launch_pair(p, op_dtype, stream);
+  }
+  return rc;
 }
 
 extern "C" int glr_local_attn_bwd(const void* vt, const void* gram, const void* tp, const float* tnorm,
                                   const int32_t* sent_slot0, const int32_t* cap_lens,
                                   const int32_t* tile_first, const int32_t* order, const int32_t* tile_nsub,
-                                  int n_tiles, int n_sent, int B_img, int D, int S_eff, float temp1, float temp2,
-                                  float temp3, int agg, float eps, const float* sim, const float* dsim, int ld_sim,
-                                  const float* lse, const float* wstat, void* xout, void* aout, float* gamma,
-                                  float* beta, int op_dtype, void* stream) {
+                                  const int32_t* item_tile, int n_items, int n_tiles, int n_sent, int B_img, int D,
+                                  int S_eff, float temp1, float temp2, float temp3, int agg, float eps,
+                                  const float* sim, const float* dsim, int ld_sim, const float* lse,
+                                  const float* wstat, void* xout, void* aout, float* gamma, float* beta,
+                                  int op_dtype, void* stream) {
   LaParams p;
   const int rc = fill_common(p, vt, gram, tp, tnorm, sent_slot0, cap_lens, tile_first, order, tile_nsub, n_tiles,
                              n_sent, B_img, D, S_eff, temp1, temp2, temp3, agg, eps, op_dtype);
   if (rc != GLR_OK) return rc;
-  if (!sim || !dsim || !lse || !wstat || !xout || !aout || !gamma || !beta) return GLR_EINVAL;
+  if (!sim || !dsim || !lse || !wstat || !xout || !aout || !gamma || !beta || !item_tile || n_items <= 0) return GLR_EINVAL;
   if (agg == GLR_AGG_MAX) return GLR_EINVAL;      // max aggregation is inference-only (gloria_model.py:199)
   p.sim = const_cast<float*>(sim); p.dsim = dsim; p.ld_sim = ld_sim; p.lse = const_cast<float*>(lse);
   p.wstat = const_cast<float*>(wstat); p.xout = (unsigned char*)xout; p.aout = (unsigned char*)aout;
-  p.gamma = gamma; p.beta = beta;
+  p.gamma = gamma; p.beta = beta; p.item_tile = item_tile; p.n_items = n_items;
   return launch<true>(p, op_dtype, stream);
 }
 
 #ifdef GLR_STAMPS
-// diagnostic build only: device buffer of [grid][8] u64 receiving s_memtime stamps of every K1 launch
+// diagnostic build only: device buffer of [grid][12] u64 receiving s_memtime stamps of every K1 launch
 extern "C" void glr_debug_set_stamps(void* buf) { g_stamps = (unsigned long long*)buf; }
 #endif

@@ -60,6 +60,31 @@ extern "C" int glr_plan_tiles(const int32_t* cap_lens, int n_sent, int capacity,
   return (int)members.size();
 }
 
+extern "C" int glr_plan_items(const int32_t* tile_nsub, const int32_t* tile_first, int n_tiles, int allow_pairs,
+                              int max_pair_seg, int32_t* single_tile, int32_t* pair_tile, int32_t* all_tile,
+                              int32_t* counts) {
+  if (!tile_nsub || !tile_first || !single_tile || !pair_tile || !all_tile || !counts || n_tiles <= 0) return GLR_EINVAL;
+  int ns = 0, np = 0, na = 0;
+  auto pairable = [&](int t) {
+    return t < n_tiles && tile_nsub[t] == 0 && tile_first[t + 1] - tile_first[t] <= max_pair_seg;
+  };
+  for (int t = 0; t < n_tiles;) {
+    if (tile_nsub[t] < 0) return GLR_EINVAL;         // a continuation tile cannot start an item
+    if (tile_nsub[t] > 1) {                          // multi-tile sentence: one item, handled in sweeps
+      single_tile[ns++] = t; all_tile[na++] = t;
+      t += tile_nsub[t];
+    } else if (allow_pairs && pairable(t) && pairable(t + 1)) {
+      pair_tile[np++] = t; all_tile[na++] = t; all_tile[na++] = t + 1;
+      t += 2;
+    } else {
+      single_tile[ns++] = t; all_tile[na++] = t;
+      t += 1;
+    }
+  }
+  counts[0] = ns; counts[1] = np; counts[2] = na;
+  return GLR_OK;
+}
+
 namespace {
 
 // grid (S_pad/64, D/64, B), 256 threads: one 64(feature) x 64(region) tile.

@@ -26,12 +26,13 @@ SYMBOLS = {
     "glr_tile_capacity": (c_int, [c_int]),
     "glr_plan_tiles_bound": (c_int, [c_void_p, c_int, c_int]),
     "glr_plan_tiles": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "glr_plan_items": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "glr_pack_regions": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "glr_pack_words": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                c_int, c_int, c_int, c_void_p]),
-    "glr_local_attn_fwd": (c_int, [c_void_p] * 9 + [c_int] * 5 + [c_float] * 3 + [c_int, c_float, c_void_p, c_int,
+    "glr_local_attn_fwd": (c_int, [c_void_p] * 10 + [c_int, c_void_p] + [c_int] * 6 + [c_float] * 3 + [c_int, c_float, c_void_p, c_int,
                                    c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
-    "glr_local_attn_bwd": (c_int, [c_void_p] * 9 + [c_int] * 5 + [c_float] * 3 + [c_int, c_float, c_void_p, c_void_p,
+    "glr_local_attn_bwd": (c_int, [c_void_p] * 10 + [c_int] * 6 + [c_float] * 3 + [c_int, c_float, c_void_p, c_void_p,
                                    c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                    c_void_p]),      # sim, dsim, ld, lse, wstat, xout, aout, gamma, beta, dtype, stream
     "glr_dual_ce_fwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
@@ -104,7 +105,7 @@ def require_cuda(*tensors):
 class TilePlan:
     """Sentence -> word-slot packing (host planning by glr_plan_tiles + device copies)."""
 
-    def __init__(self, cap_lens, device, capacity=TILE_WORDS):
+    def __init__(self, cap_lens, device, capacity=TILE_WORDS, allow_pairs=True):
         cl = np.ascontiguousarray(np.asarray(cap_lens, dtype=np.int32))
         n = int(cl.shape[0])
         L = lib()
@@ -120,19 +121,34 @@ class TilePlan:
                               nsub.ctypes.data_as(c_void_p))
         if nt <= 0:
             raise ValueError(f"glr_plan_tiles failed ({nt})")
+        singles = np.zeros(nt, dtype=np.int32)
+        pairs = np.zeros(nt, dtype=np.int32)
+        alls = np.zeros(nt, dtype=np.int32)
+        counts = np.zeros(3, dtype=np.int32)
+        rc = L.glr_plan_items(nsub.ctypes.data_as(c_void_p), tile_first.ctypes.data_as(c_void_p), nt,
+                              1 if (allow_pairs and capacity == TILE_WORDS) else 0, 16,
+                              singles.ctypes.data_as(c_void_p), pairs.ctypes.data_as(c_void_p),
+                              alls.ctypes.data_as(c_void_p), counts.ctypes.data_as(c_void_p))
+        if rc != 0:
+            raise ValueError(f"glr_plan_items failed ({rc})")
+        self.n_single, self.n_pair, self.n_all = (int(c) for c in counts)
         self.capacity = capacity
         self.cap_lens_host = cl
         self.n_sent, self.n_tiles, self.n_slots = n, nt, nt * TILE_WORDS
         self.sent_slot0_host = slot0
         self.n_words = int(cl.sum())
-        pack = np.concatenate([cl, slot0, tile_first[: nt + 1], order, nsub[:nt]]).astype(np.int32)
+        pack = np.concatenate([cl, slot0, tile_first[: nt + 1], order, nsub[:nt], singles[:self.n_single],
+                               pairs[:self.n_pair], alls[:self.n_all]]).astype(np.int32)
         dev = torch.from_numpy(pack).to(device, non_blocking=True)
         o = 0
         self.cap_lens = dev[o:o + n]; o += n
         self.sent_slot0 = dev[o:o + n]; o += n
         self.tile_first = dev[o:o + nt + 1]; o += nt + 1
         self.order = dev[o:o + bound]; o += bound
-        self.tile_nsub = dev[o:o + nt]
+        self.tile_nsub = dev[o:o + nt]; o += nt
+        self.single_tile = dev[o:o + self.n_single]; o += self.n_single
+        self.pair_tile = dev[o:o + self.n_pair]; o += self.n_pair
+        self.all_tile = dev[o:o + self.n_all]
         self._dev = dev
         self._word_index = None
 

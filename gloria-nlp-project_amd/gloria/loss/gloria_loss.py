@@ -100,10 +100,15 @@ def _pack_operands(img_features, words, no_attn_vec, cap_lens, o):
     return plan, code, vt, gram, tp, tnorm, s_eff, s_pad, shift
 
 
-def _k1_args(plan, vt, gram, tp, tnorm, B, D, s_eff, o):
-    return (N.ptr(vt), N.ptr(gram), N.ptr(tp), N.ptr(tnorm), N.ptr(plan.sent_slot0), N.ptr(plan.cap_lens),
-            N.ptr(plan.tile_first), N.ptr(plan.order), N.ptr(plan.tile_nsub), plan.n_tiles, plan.n_sent, B, D,
-            s_eff, o.temp1, o.temp2, o.temp3, N.AGG[o.agg], o.eps)
+def _k1_args(plan, vt, gram, tp, tnorm, B, D, s_eff, o, backward=False):
+    head = (N.ptr(vt), N.ptr(gram), N.ptr(tp), N.ptr(tnorm), N.ptr(plan.sent_slot0), N.ptr(plan.cap_lens),
+            N.ptr(plan.tile_first), N.ptr(plan.order), N.ptr(plan.tile_nsub))
+    if backward:
+        items = (N.ptr(plan.all_tile), plan.n_all)
+    else:
+        items = (N.ptr(plan.single_tile) if plan.n_single else None, plan.n_single,
+                 N.ptr(plan.pair_tile) if plan.n_pair else None, plan.n_pair)
+    return head + items + (plan.n_tiles, plan.n_sent, B, D, s_eff, o.temp1, o.temp2, o.temp3, N.AGG[o.agg], o.eps)
 
 
 class LocalSimFn(torch.autograd.Function):
@@ -182,7 +187,7 @@ class LocalSimFn(torch.autograd.Function):
             gamma = torch.empty(B, ns, dtype=torch.float32, device=dev)
             beta = torch.empty(B, ns, dtype=torch.float32, device=dev)
             g = dsim.float().contiguous()
-            N.check(L.glr_local_attn_bwd(*_k1_args(plan, vt, gram, tp, tnorm, B, D, s_eff, o), N.ptr(sim), N.ptr(g),
+            N.check(L.glr_local_attn_bwd(*_k1_args(plan, vt, gram, tp, tnorm, B, D, s_eff, o, True), N.ptr(sim), N.ptr(g),
                                          plan.n_sent, N.ptr(lse), N.ptr(wstat), N.ptr(xout), N.ptr(aout),
                                          N.ptr(gamma), N.ptr(beta), code, N.stream()), "glr_local_attn_bwd")
             # gradient GEMMs (plain library GEMMs on the kernel's outputs)

@@ -78,6 +78,17 @@ int glr_plan_tiles_bound(const int32_t* cap_lens, int n_sent, int capacity);
 int glr_plan_tiles(const int32_t* cap_lens, int n_sent, int capacity, int32_t* sent_slot0,
                    int32_t* tile_first, int32_t* order, int32_t* tile_nsub);
 
+/* Work items of the local-attention kernels.  With allow_pairs, two consecutive ordinary tiles that hold
+ * at most max_pair_seg (16) sentences each become ONE forward work item: a workgroup then streams vt[b] and
+ * gram[b] once for 128 words (the streams are the bound).  Outputs (each must hold n_tiles ints):
+ *   single_tile  first tile of every un-paired item (ordinary tile or head of a multi-tile sentence)
+ *   pair_tile    first tile of every pair
+ *   all_tile     every item-head tile with pairs expanded (the backward kernel works tile by tile)
+ *   counts[3]    number of entries of the three lists
+ */
+int glr_plan_items(const int32_t* tile_nsub, const int32_t* tile_first, int n_tiles, int allow_pairs,
+                   int max_pair_seg, int32_t* single_tile, int32_t* pair_tile, int32_t* all_tile, int32_t* counts);
+
 /* ------------------------------------------------------------------------------------------
  * Operand packing (device).  HBM-bound layout/convert kernels.
  *
@@ -118,6 +129,8 @@ int glr_pack_words(const void* words_emb, int in_dtype, const int32_t* sent_slot
  *   tp, tnorm    packed words of ALL sentences (glr_pack_words)
  *   sent_slot0, cap_lens   [n_sent] device int32 (same arrays as given to glr_pack_words)
  *   tile_first, order, tile_nsub   device int32 copies of the glr_plan_tiles outputs
+ *   single_tile/n_single, pair_tile/n_pair (fwd), item_tile/n_items (bwd: the all_tile list)
+ *                device int32 copies of the glr_plan_items outputs
  *   sim          fp32 [B_img, ld_sim]; column = sentence id (fwd: out, bwd: in)
  *   lse          fp32 [B_img, n_sent, S_pad]: log-sum-exp over the words of sentence i of the
  *                scores of region r (fwd: optional out, needed by bwd)
@@ -140,17 +153,19 @@ int glr_pack_words(const void* words_emb, int in_dtype, const int32_t* sent_slot
  */
 int glr_local_attn_fwd(const void* vt, const void* gram, const void* tp, const float* tnorm,
                        const int32_t* sent_slot0, const int32_t* cap_lens, const int32_t* tile_first,
-                       const int32_t* order, const int32_t* tile_nsub, int n_tiles, int n_sent, int B_img,
-                       int D, int S_eff, float temp1, float temp2, float temp3, int agg, float eps,
-                       float* sim, int ld_sim, float* lse, float* wstat, float* attn, const int64_t* attn_off,
-                       int strip, int pair_only, int img_offset, int op_dtype, void* stream);
+                       const int32_t* order, const int32_t* tile_nsub, const int32_t* single_tile, int n_single,
+                       const int32_t* pair_tile, int n_pair, int n_tiles, int n_sent, int B_img, int D, int S_eff,
+                       float temp1, float temp2, float temp3, int agg, float eps, float* sim, int ld_sim,
+                       float* lse, float* wstat, float* attn, const int64_t* attn_off, int strip, int pair_only,
+                       int img_offset, int op_dtype, void* stream);
 
 int glr_local_attn_bwd(const void* vt, const void* gram, const void* tp, const float* tnorm,
                        const int32_t* sent_slot0, const int32_t* cap_lens, const int32_t* tile_first,
-                       const int32_t* order, const int32_t* tile_nsub, int n_tiles, int n_sent, int B_img,
-                       int D, int S_eff, float temp1, float temp2, float temp3, int agg, float eps,
-                       const float* sim, const float* dsim, int ld_sim, const float* lse, const float* wstat,
-                       void* xout, void* aout, float* gamma, float* beta, int op_dtype, void* stream);
+                       const int32_t* order, const int32_t* tile_nsub, const int32_t* item_tile, int n_items,
+                       int n_tiles, int n_sent, int B_img, int D, int S_eff, float temp1, float temp2, float temp3,
+                       int agg, float eps, const float* sim, const float* dsim, int ld_sim, const float* lse,
+                       const float* wstat, void* xout, void* aout, float* gamma, float* beta, int op_dtype,
+                       void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * K2  dual cross-entropy on a square similarity matrix (labels = arange).

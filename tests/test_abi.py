@@ -61,6 +61,27 @@ def test_plan_tiles_packing():
     assert p.n_words == sum(lens)
 
 
+def test_plan_items_pairing():
+    from gloria import _native as N
+    # 5 ordinary tiles worth of 30-word sentences, one 100-word sentence (2 tiles), then many 1-word ones
+    lens = [30, 30] * 5 + [100] + [1] * 40
+    p = N.TilePlan(lens, "cpu")
+    singles, pairs, alls = p.single_tile.numpy(), p.pair_tile.numpy(), p.all_tile.numpy()
+    nsub = p.tile_nsub.numpy()
+    tf = p.tile_first.numpy()
+    covered = []
+    for t in pairs:
+        assert nsub[t] == 0 and nsub[t + 1] == 0
+        assert tf[t + 1] - tf[t] <= 16 and tf[t + 2] - tf[t + 1] <= 16     # pair tiles hold <= 16 sentences
+        covered += [t, t + 1]
+    for t in singles:
+        covered += list(range(t, t + max(nsub[t], 1)))
+    assert sorted(covered) == list(range(p.n_tiles))                       # every tile exactly once
+    assert sorted(alls.tolist()) == sorted([t for t in range(p.n_tiles) if nsub[t] >= 0])
+    # fp32 plans (32-word capacity) are never paired
+    assert N.TilePlan(lens, "cpu", 32).n_pair == 0
+
+
 def test_plan_rejects_bad_lengths():
     from gloria import _native as N
     with pytest.raises(ValueError):
