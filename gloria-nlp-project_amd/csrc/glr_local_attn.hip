@@ -84,6 +84,7 @@ struct LaParams {
   int off_img, off_small;
 #ifdef GLR_STAMPS
   unsigned long long* stamps;   // diagnostic build only: [grid][12] s_memtime at phase boundaries
+  unsigned long long* stamps2;  // same, for the pair kernel's grid
 #endif
 };
 
@@ -96,8 +97,17 @@ struct LaParams {
       p.stamps[(size_t)blockIdx.x * 12 + (i)] = t_;                                          \
     }                                                                                       \
   } while (0)
+#define GLR_STAMP2(i)                                                                       \
+  do {                                                                                      \
+    if (tid == 0 && p.stamps2) {                                                            \
+      unsigned long long t_;                                                                \
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");            \
+      p.stamps2[(size_t)blockIdx.x * 12 + (i)] = t_;                                         \
+    }                                                                                       \
+  } while (0)
 #else
 #define GLR_STAMP(i)
+#define GLR_STAMP2(i)
 #endif
 
 __device__ __forceinline__ unsigned lds_addr(const void* p) {
@@ -744,6 +754,7 @@ __global__ void __launch_bounds__(NTHR) k_local_attn_pair(LaParams p) {
   const int xcd = blockIdx.x & 7, qq = blockIdx.x >> 3;
   const int b = (qq / p.n_items) * 8 + xcd;
   if (b >= p.B_img) return;
+  GLR_STAMP2(0);
   const int tile0 = p.item_tile[qq % p.n_items];
 
   const int S_pad = p.S_pad, D = p.D;
@@ -802,6 +813,7 @@ __global__ void __launch_bounds__(NTHR) k_local_attn_pair(LaParams p) {
 #pragma unroll
     for (int q = 0; q < 16; ++q) { accA[j][q] = 0.f; accB[j][q] = 0.f; }
   __syncthreads();
+  GLR_STAMP2(1);
   stream_gemm<O, false, 2>(accA, accB, 0, ring, (2 * tw + S_pad) * CB, p.tp + (size_t)tile0 * TW * rowbytes1, rowbytes1,
                            vt_b, rowbytes1, S_pad, (int)(rowbytes1 / CB), nullptr, 0, wave, lane, wm, wg, nrb, tw);
 
@@ -844,8 +856,11 @@ __global__ void __launch_bounds__(NTHR) k_local_attn_pair(LaParams p) {
     }
     __syncthreads();
   };
+  GLR_STAMP2(2);
   walk(accA, 0);
+  GLR_STAMP2(3);
   walk(accB, 1);
+  GLR_STAMP2(4);
 
   // ================= P2: a1, e2 from the scores in registers; LDS images; per-word Z and dot~ =================
   auto p2 = [&](f32x16 (&acc)[3], int t) {
@@ -898,7 +913,9 @@ __global__ void __launch_bounds__(NTHR) k_local_attn_pair(LaParams p) {
   // NB: the images alias the score tile and the tail of the P1 ring, both dead now; the lse tables live
   // above the images until P2 of both tiles is done
   p2(accA, 0);
+  GLR_STAMP2(5);
   p2(accB, 1);
+  GLR_STAMP2(6);
 
   // ================= P3 (both tiles, one stream of gram[b]); 2-deep ring over the dead lse tables =================
   stream_gemm<O, true, 2, 2>(accA, accB, IMG, ring3, S_pad * CB, nullptr, 0, gram_b, rowbytes2, S_pad,
@@ -962,12 +979,16 @@ __global__ void __launch_bounds__(NTHR) k_local_attn_pair(LaParams p) {
     }
     __syncthreads();
   };
+  GLR_STAMP2(7);
   p4(accA, 0);
+  GLR_STAMP2(8);
   p4(accB, 1);
+  GLR_STAMP2(9);
 }
 
 #ifdef GLR_STAMPS
 unsigned long long* g_stamps = nullptr;
+unsigned long long* g_stamps2 = nullptr;
 #endif
 
 int carve(LaParams& p, int op_dtype, int S_pad) {
@@ -1044,6 +1065,7 @@ int fill_common(LaParams& p, const void* vt, const void* gram, const void* tp, c
   p.lse = nullptr; p.wstat = nullptr; p.sim = nullptr; p.ld_sim = 0;
 #ifdef GLR_STAMPS
   p.stamps = g_stamps;
+  p.stamps2 = g_stamps2;
 #endif
   return GLR_OK;
 }
@@ -1103,4 +1125,5 @@ extern "C" int glr_local_attn_bwd(const void* vt, const void* gram, const void* 
 #ifdef GLR_STAMPS
 // diagnostic build only: device buffer of [grid][12] u64 receiving s_memtime stamps of every K1 launch
 extern "C" void glr_debug_set_stamps(void* buf) { g_stamps = (unsigned long long*)buf; }
+extern "C" void glr_debug_set_stamps_pair(void* buf) { g_stamps2 = (unsigned long long*)buf; }
 #endif

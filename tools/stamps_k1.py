@@ -24,8 +24,22 @@ def run():
     if bwd:
         l0, l1 = gl.dual_cross_entropy(sim); (l0 + l1).backward()
 run(); torch.cuda.synchronize()
+buf2 = torch.zeros(grid * 12, dtype=torch.int64, device=dev)
+L.glr_debug_set_stamps_pair.argtypes = [ctypes.c_void_p]
 L.glr_debug_set_stamps(ctypes.c_void_p(buf.data_ptr()))
+L.glr_debug_set_stamps_pair(ctypes.c_void_p(buf2.data_ptr()))
 run(); torch.cuda.synchronize()
+if not bwd:
+    s2 = buf2.cpu().numpy().reshape(grid, 12)
+    s2 = s2[s2[:, 0] > 0]
+    if len(s2):
+        n2 = ["setup (plan loads, tables)", "P1 gemm (128 words)", "walk A", "walk B", "P2 A", "P2 B", "P3 gemm (128 words)",
+              "P4 A", "P4 B"]
+        d2 = np.diff(s2[:, :10].astype(np.float64), axis=1)
+        t2 = (s2[:, 9] - s2[:, 0]).astype(np.float64)
+        print(f"fwd PAIR kernel: workgroups {len(s2)}, median cycles per pair {np.median(t2):.0f}")
+        for i, n in enumerate(n2):
+            print(f"  {n:28s} median {np.median(d2[:, i]):9.0f}  share {np.median(d2[:, i]) / np.median(t2) * 100:5.1f}%")
 st = buf.cpu().numpy().reshape(grid, 12)
 st = st[st[:, 0] > 0]
 if bwd:
