@@ -137,9 +137,10 @@ constexpr int NBUF = 4;     // ring depth
 constexpr int PD = 3;       // chunks issued ahead of the one being consumed
 
 // acc[j] (+)= A(tw words x K) . Bt(brows x K)^T for this wave's blocks.
-//   A_RES = false: A rows stream from `asrc` (tw rows, pitch apitch bytes) together with B.
+//   A_RES = false: A rows stream from `asrc` (tw rows per 64-row tile block, apitch = K bytes per row) together with B.
 //   A_RES = true : A fragments come from the LDS image `aimg` ([word][k], pitch aimg_pitch bytes).
-// B rows stream from `bsrc` (brows rows, pitch bpitch bytes).  K bytes = nchunk * CHB.
+// B rows stream from `bsrc` (one block of brows rows).  K bytes = nchunk * CHB.  Both operands are K-tiled
+// (glr_tile_k: [K chunk][row][CHB bytes] per block).
 // NPWC = LDS-DMA pieces every wave issues per chunk (compile time, so every vmcnt wait is an immediate).
 //
 // Ring protocol (NBUF buffers, PD chunks ahead, ONE barrier per chunk): at step c every wave waits
@@ -183,20 +184,27 @@ __device__ __forceinline__ void stream_gemm_n(f32x16 (&acc)[3], f32x16 (&acc2)[3
   // last piece: two waves then write the same bytes to the same LDS slot, which is harmless)
   const unsigned char* psrc[NPWC];
   unsigned pdst[NPWC];
+  int pstep[NPWC];
 #pragma unroll
   for (int i = 0; i < NPWC; ++i) {
     const int k = min(wave + 8 * i, winstr - 1);
     const int row = k * RPI + prow;
     const int g = pslot ^ ((row / RPB) & (PPR - 1));
-    // A row r of the ring = populated row (r % tw) of tile (r / tw)
-    psrc[i] = ((row < arows) ? (asrc + ((size_t)(row / tw) * TW + (row % tw)) * apitch)
-                             : (bsrc + (size_t)(row - arows) * bpitch)) + g * 16;
+    // Operands are K-TILED in HBM (glr_tile_k): a block of R rows is stored [K chunk][row][CHB bytes], so
+    // every DMA piece reads 1 KiB of CONTIGUOUS memory (row-major operands gave 64-byte fragments of 16
+    // different rows per piece: half of every 128-byte line fetched twice, 27 B/clk/CU instead of ~48).
+    // A row r of the ring = populated row (r % tw) of tile (r / tw); a tile block holds TW rows per chunk.
+    const bool is_a = row < arows;
+    const int tl = row / tw, rr = row - tl * tw;
+    const size_t off = is_a ? (size_t)tl * TW * apitch + (size_t)rr * CHB : (size_t)(row - arows) * CHB;
+    psrc[i] = (is_a ? asrc : bsrc) + off + g * 16;
+    pstep[i] = (is_a ? TW : brows) * CHB;                    // bytes from one K chunk to the next
     pdst[i] = ring_lds + k * 1024;
   }
   auto issue = [&](int c) {
     const unsigned boff = (c % NB) * buf_bytes;
 #pragma unroll
-    for (int i = 0; i < NPWC; ++i) glds16(psrc[i] + (size_t)c * CHB, pdst[i] + boff);
+    for (int i = 0; i < NPWC; ++i) glds16(psrc[i] + (size_t)((unsigned)c * (unsigned)pstep[i]), pdst[i] + boff);
   };
   auto compute = [&](int c) {
     const unsigned char* rb = ring + (c % NB) * buf_bytes;
@@ -275,7 +283,11 @@ __device__ __forceinline__ float row_sum16(float v) {
   return v;
 }
 
-template <typename O, bool BWD>
+// FULL: S_pad == GLR_MAX_SPAD (the production shape, 361/362 regions): every wave owns three valid region
+// blocks, so the per-block guards vanish at compile time (a guarded LDS access compiles to its own basic
+// block with a full s_waitcnt: 48 serialised LDS round trips per phase otherwise).
+#define GLR_BLK_OK(blk) (FULL || (blk) < nrb)
+template <typename O, bool BWD, bool FULL>
 __global__ void __launch_bounds__(NTHR) k_local_attn(LaParams p) {
   constexpr int ESZ = O::ESZ, CB = CHB;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -302,14 +314,14 @@ __global__ void __launch_bounds__(NTHR) k_local_attn(LaParams p) {
   if (nsub < 0) return;
   if (nsub == 0) nsub = 1;
 
-  const int S_pad = p.S_pad, D = p.D;
+  const int S_pad = FULL ? GLR_MAX_SPAD : p.S_pad, D = p.D;
   // LDS tile pitches are compile-time constants (sized for GLR_MAX_SPAD) so that every per-element
   // LDS address is one lane-dependent base + an immediate offset
   constexpr int SCP = GLR_MAX_SPAD;                  // fp32 score tile pitch (floats)
   constexpr int IMP = GLR_MAX_SPAD * ESZ + 16;       // LDS image pitch (bytes)
   const int nrb = S_pad >> 5;
-  const int tw = p.tw;
-  const bool wactive = wm * 32 < tw;
+  const int tw = ESZ == 2 ? TW : p.tw;               // bf16 tiles are always full width
+  const bool wactive = ESZ == 2 || wm * 32 < tw;
 
   unsigned char* ring = smem;                // ring buffers / score tile / rho share [0, off_img)
   float* sc = reinterpret_cast<float*>(smem);
@@ -422,7 +434,7 @@ __global__ void __launch_bounds__(NTHR) k_local_attn(LaParams p) {
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
         const int blk = wg + 4 * j;
-        if (blk < nrb && wactive) {
+        if (GLR_BLK_OK(blk) && wactive) {
 #pragma unroll
           for (int q = 0; q < 16; ++q) {
             const int word = wm * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
@@ -506,7 +518,7 @@ __global__ void __launch_bounds__(NTHR) k_local_attn(LaParams p) {
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
           const int blk = wg + 4 * j;
-          if (blk < nrb) {
+          if (GLR_BLK_OK(blk)) {
             const int region = blk * 32 + l31;
             // branch-free: invalid (empty slot / padded region) elements are zeroed
             const bool ok = sg >= 0 && region < p.S_eff;
@@ -560,7 +572,7 @@ __global__ void __launch_bounds__(NTHR) k_local_attn(LaParams p) {
 #pragma unroll
           for (int j = 0; j < 3; ++j) {
             const int blk = wg + 4 * j;
-            if (blk < nrb) v += O::to_f32(img + word * IMP + (blk * 32 + l31) * ESZ) * acc[j][q];
+            if (GLR_BLK_OK(blk)) v += O::to_f32(img + word * IMP + (blk * 32 + l31) * ESZ) * acc[j][q];
           }
         }
         v = row_sum16(v);
@@ -650,7 +662,7 @@ __global__ void __launch_bounds__(NTHR) k_local_attn(LaParams p) {
             if (cur >= 0 && do_rho) {
 #pragma unroll
               for (int j = 0; j < 3; ++j)
-                if (wg + 4 * j < nrb) atomicAdd(&rho[cur * S_pad + (wg + 4 * j) * 32 + l31], run[j]);
+                if (GLR_BLK_OK(wg + 4 * j)) atomicAdd(&rho[cur * S_pad + (wg + 4 * j) * 32 + l31], run[j]);
             }
             cur = rrow;
             run[0] = run[1] = run[2] = 0.f;
@@ -658,7 +670,7 @@ __global__ void __launch_bounds__(NTHR) k_local_attn(LaParams p) {
 #pragma unroll
           for (int j = 0; j < 3; ++j) {
             const int blk = wg + 4 * j;
-            if (blk < nrb) {
+            if (GLR_BLK_OK(blk)) {
               const int region = blk * 32 + l31;
               const float a1 = a1r[j][q];
               const bool ok = sg >= 0 && region < p.S_eff;
@@ -672,7 +684,7 @@ __global__ void __launch_bounds__(NTHR) k_local_attn(LaParams p) {
         if (cur >= 0 && do_rho) {
 #pragma unroll
           for (int j = 0; j < 3; ++j)
-            if (wg + 4 * j < nrb) atomicAdd(&rho[cur * S_pad + (wg + 4 * j) * 32 + l31], run[j]);
+            if (GLR_BLK_OK(wg + 4 * j)) atomicAdd(&rho[cur * S_pad + (wg + 4 * j) * 32 + l31], run[j]);
         }
       }
       __syncthreads();
@@ -693,7 +705,7 @@ __global__ void __launch_bounds__(NTHR) k_local_attn(LaParams p) {
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
               const int blk = wg + 4 * j;
-              if (blk < nrb && wactive) {
+              if (GLR_BLK_OK(blk) && wactive) {
                 const int region = blk * 32 + l31;
                 const bool ok = sg >= 0 && region < p.S_eff;
                 const float a1 = a1r[j][q];
@@ -730,19 +742,29 @@ __global__ void __launch_bounds__(NTHR) k_local_attn(LaParams p) {
 // ------------------------------------------------------------------------------------------
 // Forward for a PAIR of ordinary tiles (128 words) of one image: vt[b] AND gram[b] are streamed once
 // for both tiles (the streams are L2->LDS bandwidth bound, ~27 B/clk/CU, so bytes per word decide the
-// time).  Both tiles' scores live in registers (2 x 48 fp32) through the statistics walks and P2;
-// LDS:  [0, 2*IMG)      images of tile A and B        | aliased earlier by the P1 ring / score tile
-//       [2*IMG, +TAB)   lse tables [2][16][S_pad]     | aliased later by the 2-deep P3 ring
+// time).  Both tiles' scores stay in registers (2 x 48 fp32) from P1 to P2.
+//
+// Word softmax statistics WITHOUT a score tile in LDS: in the accumulator layout a lane owns 16 words of
+// one region column, and the words of a sentence are a run along the register index, so each lane reduces
+// its runs in registers and publishes one value per (run, region):
+//   pass 1  run maximum  -> ds_max_f32 on mx[sentence][region]           (exact, order independent)
+//   pass 2  run sum of exp(s - max) -> plain store to ps[word block, half wave][sentence][region]
+//           (one writer per entry; the four partial tables are summed in fixed order afterwards:
+//            bitwise reproducible)
+// LDS:  [0, 2*IMG)      images of tile A and B   | earlier: P1 ring, then the mx / ps tables
+//       [2*IMG, +TAB)   lse tables (log2 units) [PAIR_MAXSEG][S_pad] | later: the 2-deep P3 ring
 //       small           segment tables, reductions
-// Tiles with more than PAIR_MAXSEG sentences are not paired by the planner.
+// A pair holds at most PAIR_MAXSEG sentences in total (planner: glr_plan_items).
 constexpr int PAIR_MAXSEG = 16;
 
 template <typename O>
 __global__ void __launch_bounds__(NTHR) k_local_attn_pair(LaParams p) {
   constexpr int ESZ = O::ESZ, CB = CHB;
-  constexpr int SCP = GLR_MAX_SPAD;
-  constexpr int IMP = GLR_MAX_SPAD * ESZ + 16;
+  constexpr int SP = GLR_MAX_SPAD;               // this kernel is built for S_pad == GLR_MAX_SPAD only (launch_pair checks)
+  constexpr int NRB = SP / 32;
+  constexpr int IMP = SP * ESZ + 16;
   constexpr int IMG = TW * IMP;
+  constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   const int tid = threadIdx.x;
@@ -756,54 +778,51 @@ __global__ void __launch_bounds__(NTHR) k_local_attn_pair(LaParams p) {
   if (b >= p.B_img) return;
   GLR_STAMP2(0);
   const int tile0 = p.item_tile[qq % p.n_items];
-
-  const int S_pad = p.S_pad, D = p.D;
-  const int nrb = S_pad >> 5;
-  const int tw = p.tw;
+  const int D = p.D;
 
   unsigned char* ring = smem;
-  float* sc = reinterpret_cast<float*>(smem);
   unsigned char* img0 = smem;
-  float* tab = reinterpret_cast<float*>(smem + p.off_img);       // [2][PAIR_MAXSEG][S_pad]
+  float* ps = reinterpret_cast<float*>(smem);                    // [4][PAIR_MAXSEG][SP] partial sums per (word block, half wave)
+  float* tab = reinterpret_cast<float*>(smem + p.off_img);       // [PAIR_MAXSEG][SP]   lse, log2 units
+  float* mx = tab + PAIR_MAXSEG * SP;                            // [PAIR_MAXSEG][SP]   segment maxima, log2 units
   unsigned char* ring3 = smem + p.off_img;
-  int* seg_w0 = reinterpret_cast<int*>(smem + p.off_small);      // [2][TW] each
-  int* seg_n = seg_w0 + 2 * TW;
-  int* seg_sent = seg_n + 2 * TW;
-  int* wseg = seg_sent + 2 * TW;
-  float* red = reinterpret_cast<float*>(wseg + 2 * TW);          // [2][8][TW]
-  float* zsum = red + 16 * TW;                                   // [2][TW]
-  float* dsum = zsum + 2 * TW;                                   // [2][TW]
-  float* exs = dsum + 2 * TW;                                    // [TW]
-  int* diag = reinterpret_cast<int*>(exs + TW);                  // [2][2]
-  int* nsegs = diag + 4;                                         // [2]
+  signed char* wsegb = reinterpret_cast<signed char*>(smem + p.off_small);   // [2 * TW] sentence index in the pair, -1 = empty
+  int* seg_w0 = reinterpret_cast<int*>(wsegb + 2 * TW);          // [PAIR_MAXSEG] first slot (0..127)
+  int* seg_n = seg_w0 + PAIR_MAXSEG;
+  int* seg_sent = seg_n + PAIR_MAXSEG;
+  int* misc = seg_sent + PAIR_MAXSEG;                            // [0] = sentences in the pair, [1..2] diagonal w0, n
+  float* tnl = reinterpret_cast<float*>(misc + 16);              // [2 * TW] word norms
+  float* zsum = tnl + 2 * TW;                                    // [2 * TW]
+  float* dsum = zsum + 2 * TW;                                   // [2 * TW]
+  float* red = dsum + 2 * TW;                                    // [2 tiles][2][8][TW]
 
-  const size_t rowbytes1 = (size_t)D * ESZ, rowbytes2 = (size_t)S_pad * ESZ;
-  const unsigned char* vt_b = p.vt + (size_t)b * S_pad * rowbytes1;
-  const unsigned char* gram_b = p.gram + (size_t)b * S_pad * rowbytes2;
+  const size_t rowbytes1 = (size_t)D * ESZ, rowbytes2 = (size_t)SP * ESZ;
+  const unsigned char* vt_b = p.vt + (size_t)b * SP * rowbytes1;
+  const unsigned char* gram_b = p.gram + (size_t)b * SP * rowbytes2;
 
-  // ---- segment tables of both tiles
-  if (tid < 2 * TW) wseg[tid] = -1;
-  if (tid < 4) diag[tid] = 0;
-#pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    const int tile = tile0 + t;
-    const int sf = p.tile_first[tile], ns = p.tile_first[tile + 1] - sf;
-    if (tid == 0) nsegs[t] = ns;
+  // ---- segment tables of both tiles (sentence index = position in the pair)
+  if (tid < 2 * TW) {
+    wsegb[tid] = -1;
+    tnl[tid] = p.tnorm[(size_t)tile0 * TW + tid];
+  }
+  if (tid < 3) misc[tid] = 0;
+  {
+    const int sf0 = p.tile_first[tile0], sf2 = p.tile_first[tile0 + 2];
+    const int ns = sf2 - sf0;
+    if (tid == 0) misc[0] = ns;
     if (tid < ns) {
-      const int sent = p.order[sf + tid];
-      seg_sent[t * TW + tid] = sent;
-      seg_w0[t * TW + tid] = p.sent_slot0[sent] - tile * TW;
-      seg_n[t * TW + tid] = p.cap_lens[sent];
+      const int sent = p.order[sf0 + tid];
+      seg_sent[tid] = sent;
+      seg_w0[tid] = p.sent_slot0[sent] - tile0 * TW;
+      seg_n[tid] = p.cap_lens[sent];
     }
   }
   __syncthreads();
-#pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    if (tid < nsegs[t]) {
-      const int w0 = seg_w0[t * TW + tid], n = seg_n[t * TW + tid];
-      for (int w = 0; w < n; ++w) wseg[t * TW + w0 + w] = tid;
-      if (seg_sent[t * TW + tid] == p.img_offset + b) { diag[2 * t] = w0; diag[2 * t + 1] = n; }
-    }
+  const int NS = misc[0];
+  if (tid < NS) {
+    const int w0 = seg_w0[tid], n = seg_n[tid];
+    for (int w = 0; w < n; ++w) wsegb[w0 + w] = (signed char)tid;
+    if (seg_sent[tid] == p.img_offset + b) { misc[1] = w0; misc[2] = n; }
   }
 
   // ================= P1 (both tiles, one stream of vt[b]) =================
@@ -814,176 +833,231 @@ __global__ void __launch_bounds__(NTHR) k_local_attn_pair(LaParams p) {
     for (int q = 0; q < 16; ++q) { accA[j][q] = 0.f; accB[j][q] = 0.f; }
   __syncthreads();
   GLR_STAMP2(1);
-  stream_gemm<O, false, 2>(accA, accB, 0, ring, (2 * tw + S_pad) * CB, p.tp + (size_t)tile0 * TW * rowbytes1, rowbytes1,
-                           vt_b, rowbytes1, S_pad, (int)(rowbytes1 / CB), nullptr, 0, wave, lane, wm, wg, nrb, tw);
-
-  // ================= statistics walks: lse[r, sentence] of tile t into tab[t] =================
-  auto walk = [&](f32x16 (&acc)[3], int t) {
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      const int blk = wg + 4 * j;
-      if (blk < nrb) {
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-          const int word = wm * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
-          sc[word * SCP + blk * 32 + l31] = acc[j][q];
-        }
-      }
-    }
-    __syncthreads();
-    if (tid < S_pad) {
-      const int r = tid, ns = nsegs[t];
-      for (int s2 = 0; s2 < ns; ++s2) {
-        const int w0 = seg_w0[t * TW + s2], n = seg_n[t * TW + s2];
-        const float* col = sc + w0 * SCP + r;
-        float m = -INFINITY;
-        int w = 0;
-        for (; w + 4 <= n; w += 4) {
-          const float x0 = col[w * SCP], x1 = col[(w + 1) * SCP], x2 = col[(w + 2) * SCP], x3 = col[(w + 3) * SCP];
-          m = fmaxf(m, fmaxf(fmaxf(x0, x1), fmaxf(x2, x3)));
-        }
-        for (; w < n; ++w) m = fmaxf(m, col[w * SCP]);
-        float sum = 0.f;
-        for (w = 0; w + 4 <= n; w += 4) {
-          const float x0 = col[w * SCP], x1 = col[(w + 1) * SCP], x2 = col[(w + 2) * SCP], x3 = col[(w + 3) * SCP];
-          sum += (__expf(x0 - m) + __expf(x1 - m)) + (__expf(x2 - m) + __expf(x3 - m));
-        }
-        for (; w < n; ++w) sum += __expf(col[w * SCP] - m);
-        const float l = m + __logf(sum);
-        tab[(t * PAIR_MAXSEG + s2) * S_pad + r] = l;
-        if (p.lse) p.lse[((size_t)b * p.n_sent + seg_sent[t * TW + s2]) * S_pad + r] = l;
-      }
-    }
-    __syncthreads();
-  };
+  stream_gemm<O, false, 2>(accA, accB, 0, ring, (2 * TW + SP) * CB, p.tp + (size_t)tile0 * TW * rowbytes1, rowbytes1,
+                           vt_b, rowbytes1, SP, (int)(rowbytes1 / CB), nullptr, 0, wave, lane, wm, wg, NRB, TW);
   GLR_STAMP2(2);
-  walk(accA, 0);
+
+  // ================= word-softmax statistics from the scores in registers =================
+  for (int i = tid; i < NS * SP; i += NTHR) {
+    mx[i] = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) ps[k * PAIR_MAXSEG * SP + i] = 0.f;
+  }
+  // sentence ids of this lane's 16 word rows of tile t: word = wm*32 + (q&3) + 8*(q>>2) + 4*h, so the four
+  // rows of a q-group are four consecutive bytes
+  int sgA[4], sgB[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    sgA[g] = *reinterpret_cast<const int*>(wsegb + wm * 32 + 4 * h + 8 * g);
+    sgB[g] = *reinterpret_cast<const int*>(wsegb + TW + wm * 32 + 4 * h + 8 * g);
+  }
+#define GLR_SGQ(pk, q) (((pk)[(q) >> 2] << (24 - 8 * ((q) & 3))) >> 24)
+  __syncthreads();
+  const int rbase = wg * 32 + l31;              // this lane's region in block j: rbase + 128 * j
+  // pass 1: run maxima (log2 units) -> ds_max_f32.  A run ends where the next row has another sentence.
+  auto run_max = [&](f32x16 (&acc)[3], const int (&pk)[4]) {
+    float rm[3] = {-INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int sg = GLR_SGQ(pk, q);
+      const bool last = (q == 15) || (GLR_SGQ(pk, (q + 1) & 15) != sg);
+#pragma unroll
+      for (int j = 0; j < 3; ++j) rm[j] = fmaxf(rm[j], acc[j][q]);
+      if (last && sg >= 0) {
+        float* dst = mx + sg * SP + rbase;
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+          __hip_atomic_fetch_max(dst + 128 * j, rm[j] * LOG2E, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+#pragma unroll
+      for (int j = 0; j < 3; ++j) rm[j] = last ? -INFINITY : rm[j];
+    }
+  };
+  run_max(accA, sgA);
+  run_max(accB, sgB);
+  __syncthreads();
   GLR_STAMP2(3);
-  walk(accB, 1);
+  // pass 2: run sums of exp2(s*log2e - max) -> ds_add_f32 (the maximum of every element's sentence is one
+  // independent LDS read per element: no serial dependence on the run bookkeeping)
+  // (LDS float-add atomics measured ~60 cycles per wave instruction here; every (word block, half wave,
+  //  sentence, region) has exactly one writer, so plain stores into four partial tables do the same job)
+  float* psw = ps + (wm * 2 + h) * PAIR_MAXSEG * SP;
+  auto run_sum = [&](f32x16 (&acc)[3], const int (&pk)[4]) {
+    float rs[3] = {0.f, 0.f, 0.f}, nx[3];
+    {
+      const float* src = mx + max(GLR_SGQ(pk, 0), 0) * SP + rbase;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) nx[j] = src[128 * j];
+    }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int sg = GLR_SGQ(pk, q);
+      const bool last = (q == 15) || (GLR_SGQ(pk, (q + 1) & 15) != sg);
+      float m2[3];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) m2[j] = nx[j];
+      if (q < 15) {                              // next row's maxima are in flight while this row computes
+        const float* src = mx + max(GLR_SGQ(pk, (q + 1) & 15), 0) * SP + rbase;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) nx[j] = src[128 * j];
+      }
+#pragma unroll
+      for (int j = 0; j < 3; ++j) rs[j] += __builtin_amdgcn_exp2f(__builtin_fmaf(acc[j][q], LOG2E, -m2[j]));
+      if (last && sg >= 0) {
+        float* dst = psw + sg * SP + rbase;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) dst[128 * j] = rs[j];
+      }
+#pragma unroll
+      for (int j = 0; j < 3; ++j) rs[j] = last ? 0.f : rs[j];
+    }
+  };
+  run_sum(accA, sgA);
+  run_sum(accB, sgB);
+  __syncthreads();
+  if (tid < SP) {
+    for (int s2 = 0; s2 < NS; ++s2) {
+      const float sum = (ps[s2 * SP + tid] + ps[(PAIR_MAXSEG + s2) * SP + tid]) +
+                        (ps[(2 * PAIR_MAXSEG + s2) * SP + tid] + ps[(3 * PAIR_MAXSEG + s2) * SP + tid]);
+      const float l2 = mx[s2 * SP + tid] + __builtin_amdgcn_logf(sum);      // v_log_f32 = log2
+      tab[s2 * SP + tid] = l2;
+      if (p.lse) p.lse[((size_t)b * p.n_sent + seg_sent[s2]) * SP + tid] = l2 * LN2;
+    }
+  }
+  __syncthreads();
   GLR_STAMP2(4);
 
   // ================= P2: a1, e2 from the scores in registers; LDS images; per-word Z and dot~ =================
-  auto p2 = [&](f32x16 (&acc)[3], int t) {
-    unsigned char* img = img0 + t * IMG;
-    const int rslot = wg * 2 + ((lane >> 4) & 1);
-    int cur = -2;
-    float lcur[3] = {0.f, 0.f, 0.f};
+  // Branch-free: padded regions (r >= S_eff) have zero vt rows and zero Gram rows/columns, so their e2 only
+  // has to be kept out of Z (mask folded into one fma); empty word slots compute finite garbage that no
+  // sentence ever reads (a select here makes hipcc sink the LDS read + both exps into a per-element branch).
+  const float t1l = p.temp1 * LOG2E;
+  const int rslot = wg * 2 + ((lane >> 4) & 1);
+  float okr[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) okr[j] = (rbase + 128 * j < p.S_eff) ? 1.f : 0.f;
+  auto p2 = [&](f32x16 (&acc)[3], const int (&pk)[4], int t) {
+    unsigned char* imgw = img0 + t * IMG + (wm * 32 + 4 * h) * IMP + rbase * ESZ;   // + row(q) * IMP + 128 * j * ESZ
+    float* redt = red + t * 16 * TW + rslot * TW + wm * 32 + 4 * h;               // + 8 * TW (dot) + row(q)
+    float nx[3];
+    {
+      const float* src = tab + max(GLR_SGQ(pk, 0), 0) * SP + rbase;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) nx[j] = src[128 * j];
+    }
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
-      const int word = wm * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
-      const int sg = wseg[t * TW + word];
-      if (sg != cur && sg >= 0) {
-        cur = sg;
+      const int row = (q & 3) + 8 * (q >> 2);
+      float l2[3];
 #pragma unroll
-        for (int j = 0; j < 3; ++j)
-          lcur[j] = tab[(t * PAIR_MAXSEG + sg) * S_pad + min((wg + 4 * j) * 32 + l31, S_pad - 1)];
+      for (int j = 0; j < 3; ++j) l2[j] = nx[j];
+      if (q < 15) {                              // next row's lse values are in flight while this row computes
+        const float* src = tab + max(GLR_SGQ(pk, (q + 1) & 15), 0) * SP + rbase;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) nx[j] = src[128 * j];
       }
       float zacc = 0.f, dacc = 0.f;
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
-        const int blk = wg + 4 * j;
-        if (blk < nrb) {
-          const int region = blk * 32 + l31;
-          const bool ok = sg >= 0 && region < p.S_eff;
-          const float a1 = ok ? __expf(acc[j][q] - lcur[j]) : 0.f;
-          const float e2 = ok ? __expf(p.temp1 * a1) : 0.f;
-          O::from_f32(img + word * IMP + region * ESZ, e2);
-          const float e2r = ESZ == 4 ? e2 : bf2f(f2bf(e2));
-          zacc += e2r;
-          dacc += e2r * acc[j][q];
-          acc[j][q] = 0.f;
-        }
+        const float a1 = __builtin_amdgcn_exp2f(__builtin_fmaf(acc[j][q], LOG2E, -l2[j]));
+        const float e2 = __builtin_amdgcn_exp2f(t1l * a1);
+        O::from_f32(imgw + row * IMP + 128 * j * ESZ, e2);
+        const float e2r = ESZ == 4 ? e2 : bf2f(f2bf(e2));
+        zacc = __builtin_fmaf(e2r, okr[j], zacc);
+        dacc = __builtin_fmaf(e2r, acc[j][q], dacc);
+        acc[j][q] = 0.f;
       }
       const float z = row_sum16(zacc), d = row_sum16(dacc);
       if ((lane & 15) == 15) {
-        red[(0 * 8 + rslot) * TW + word] = z;
-        red[(1 * 8 + rslot) * TW + word] = d;
+        redt[row] = z;
+        redt[8 * TW + row] = d;
       }
     }
-    __syncthreads();
-    if (tid < TW) {
-      float z = 0.f, d = 0.f;
-#pragma unroll
-      for (int k = 0; k < 8; ++k) { z += red[k * TW + tid]; d += red[(8 + k) * TW + tid]; }
-      zsum[t * TW + tid] = z;
-      dsum[t * TW + tid] = d;
-    }
-    __syncthreads();
   };
-  // NB: the images alias the score tile and the tail of the P1 ring, both dead now; the lse tables live
-  // above the images until P2 of both tiles is done
-  p2(accA, 0);
+  // NB: the images alias the mx / ps tables, dead now; the lse tables live above the images until the
+  // barrier below, then the P3 ring takes their place
+  p2(accA, sgA, 0);
+  p2(accB, sgB, 1);
+  __syncthreads();
+  if (tid < 2 * TW) {
+    const float* redt = red + (tid >> 6) * 16 * TW + (tid & 63);
+    float z = 0.f, d = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { z += redt[k * TW]; d += redt[(8 + k) * TW]; }
+    zsum[tid] = z;
+    dsum[tid] = d;
+  }
   GLR_STAMP2(5);
-  p2(accB, 1);
-  GLR_STAMP2(6);
 
   // ================= P3 (both tiles, one stream of gram[b]); 2-deep ring over the dead lse tables =================
-  stream_gemm<O, true, 2, 2>(accA, accB, IMG, ring3, S_pad * CB, nullptr, 0, gram_b, rowbytes2, S_pad,
-                            (int)(rowbytes2 / CB), img0, IMP, wave, lane, wm, wg, nrb, tw);
+  stream_gemm<O, true, 2, 2>(accA, accB, IMG, ring3, SP * CB, nullptr, 0, gram_b, rowbytes2, SP,
+                            (int)(rowbytes2 / CB), img0, IMP, wave, lane, wm, wg, NRB, TW);
+  GLR_STAMP2(6);
 
   // ================= P4: |c|^2, cosine, per-sentence aggregate, diagonal attention maps =================
   auto p4 = [&](f32x16 (&acc)[3], int t) {
-    const int tile = tile0 + t;
-    const unsigned char* img = img0 + t * IMG;
+    const unsigned char* imgw = img0 + t * IMG + (wm * 32 + 4 * h) * IMP + rbase * ESZ;
+    float* redt = red + t * 16 * TW + rslot * TW + wm * 32 + 4 * h;
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
-      const int word = wm * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+      const int row = (q & 3) + 8 * (q >> 2);
       float v = 0.f;
 #pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        const int blk = wg + 4 * j;
-        if (blk < nrb) v += O::to_f32(img + word * IMP + (blk * 32 + l31) * ESZ) * acc[j][q];
-      }
+      for (int j = 0; j < 3; ++j) v += O::to_f32(imgw + row * IMP + 128 * j * ESZ) * acc[j][q];
       v = row_sum16(v);
-      if ((lane & 15) == 15) red[(wg * 2 + ((lane >> 4) & 1)) * TW + word] = v;
+      if ((lane & 15) == 15) redt[row] = v;
     }
-    __syncthreads();
-    if (tid < TW) {
-      float nn = 0.f;
-#pragma unroll
-      for (int k = 0; k < 8; ++k) nn += red[k * TW + tid];
-      const float z = zsum[t * TW + tid], dd = dsum[t * TW + tid];
-      float cosv = 0.f, nc2 = 0.f;
-      if (z > 0.f) {
-        const float iz = 1.f / z;
-        nc2 = fmaxf(nn, 0.f) * iz * iz;
-        const float den = fmaxf(p.tnorm[(size_t)tile * TW + tid] * sqrtf(nc2), p.eps);
-        cosv = dd * iz / den;
-      }
-      exs[tid] = __expf(p.temp2 * cosv);
-      if (p.wstat) {
-        float* ws = p.wstat + ((size_t)b * p.n_slots + (size_t)tile * TW + tid) * WSTAT;
-        ws[0] = z; ws[1] = cosv; ws[2] = nc2; ws[3] = 0.f;
-      }
-    }
-    __syncthreads();
-    if (tid < nsegs[t]) {
-      const int w0 = seg_w0[t * TW + tid], n = seg_n[t * TW + tid];
-      float v = 0.f;
-      if (p.agg == GLR_AGG_MAX) {
-        for (int w = 0; w < n; ++w) v = fmaxf(v, exs[w0 + w]);
-      } else {
-        for (int w = 0; w < n; ++w) v += exs[w0 + w];
-      }
-      if (p.agg == GLR_AGG_MEAN) v /= (float)n;
-      p.sim[(size_t)b * p.ld_sim + seg_sent[t * TW + tid]] = p.temp3 * __logf(v);
-    }
-    const int dw0 = diag[2 * t], dn = diag[2 * t + 1];
-    if (p.attn != nullptr && dn > 0) {
-      const int sout = p.S_eff - p.strip;
-      float* out = p.attn + p.attn_off[p.img_offset + b];
-      for (int idx = tid; idx < dn * sout; idx += NTHR) {
-        const int w = idx / sout, r = idx % sout + p.strip;
-        out[idx] = O::to_f32(img + (dw0 + w) * IMP + r * ESZ) / zsum[t * TW + dw0 + w];
-      }
-    }
-    __syncthreads();
   };
-  GLR_STAMP2(7);
   p4(accA, 0);
-  GLR_STAMP2(8);
   p4(accB, 1);
-  GLR_STAMP2(9);
+  __syncthreads();
+  GLR_STAMP2(7);
+  if (tid < 2 * TW) {            // waves 0 / 1 = tile A / B, lane = word slot
+    const float* redt = red + wave * 16 * TW + lane;
+    float nn = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) nn += redt[k * TW];
+    const float z = zsum[tid], dd = dsum[tid];
+    float cosv = 0.f, nc2 = 0.f;
+    if (z > 0.f) {
+      const float iz = 1.f / z;
+      nc2 = fmaxf(nn, 0.f) * iz * iz;
+      const float den = fmaxf(tnl[tid] * sqrtf(nc2), p.eps);
+      cosv = dd * iz / den;
+    }
+    if (p.wstat) {
+      float* ws = p.wstat + ((size_t)b * p.n_slots + (size_t)tile0 * TW + tid) * WSTAT;
+      ws[0] = z; ws[1] = cosv; ws[2] = nc2; ws[3] = 0.f;
+    }
+    // per-sentence aggregate: segmented inclusive scan along the lanes (sentences are lane runs),
+    // fixed order -> bitwise reproducible
+    const int sg = wsegb[tid];
+    float v = __expf(p.temp2 * cosv);
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const float o = __shfl_up(v, off, 64);
+      const int so = __shfl_up(sg, off, 64);
+      if (lane >= off && so == sg) v = (p.agg == GLR_AGG_MAX) ? fmaxf(v, o) : v + o;
+    }
+    const int snext = __shfl_down(sg, 1, 64);
+    if (sg >= 0 && (lane == 63 || snext != sg)) {
+      if (p.agg == GLR_AGG_MEAN) v /= (float)seg_n[sg];
+      p.sim[(size_t)b * p.ld_sim + seg_sent[sg]] = p.temp3 * __logf(v);
+    }
+  }
+  const int dw0 = misc[1], dn = misc[2];
+  if (p.attn != nullptr && dn > 0) {            // the diagonal sentence lies inside one of the two tiles
+    const int sout = p.S_eff - p.strip;
+    float* out = p.attn + p.attn_off[p.img_offset + b];
+    const unsigned char* img = img0 + (dw0 >> 6) * IMG;
+    const int dwl = dw0 & 63;
+    for (int idx = tid; idx < dn * sout; idx += NTHR) {
+      const int w = idx / sout, r = idx % sout + p.strip;
+      out[idx] = O::to_f32(img + (dwl + w) * IMP + r * ESZ) / zsum[dw0 + w];
+    }
+  }
+  GLR_STAMP2(8);
+#undef GLR_SGQ
 }
 
 #ifdef GLR_STAMPS
@@ -1002,16 +1076,17 @@ int carve(LaParams& p, int op_dtype, int S_pad) {
   return p.off_small + 12288;
 }
 
-// pair kernel: [0, 2*IMG) images | [2*IMG, +max(tables, 2-deep P3 ring)) | small
+// pair kernel: [0, 2*IMG) images (earlier: P1 ring, mx / ps tables) | lse tables, then the 2-deep P3 ring | small
 int carve_pair(LaParams& p, int op_dtype, int S_pad) {
   const int esz = op_dtype == GLR_F32 ? 4 : 2;
   const int img_bytes = TW * (GLR_MAX_SPAD * esz + 16);
-  const int tab_bytes = 2 * PAIR_MAXSEG * S_pad * 4;
+  const int tab_bytes = 2 * PAIR_MAXSEG * S_pad * 4;          // lse table + segment maxima
+  const int walk_bytes = 4 * PAIR_MAXSEG * GLR_MAX_SPAD * 4;  // partial-sum tables (alias the images)
   const int ring3 = 2 * S_pad * CHB;
   const int ring1 = NBUF * (2 * p.tw + S_pad) * CHB;
-  p.off_img = 2 * img_bytes;                       // tables / P3 ring
+  p.off_img = max(2 * img_bytes, walk_bytes);      // tables / P3 ring
   p.off_small = max(p.off_img + max(tab_bytes, ring3), ring1);
-  return p.off_small + 10240;
+  return p.off_small + 12288;
 }
 
 template <bool BWD>
@@ -1021,19 +1096,27 @@ int launch(LaParams& p, int op_dtype, void* stream) {
   const int grid = p.pair_only ? p.B_img : ((p.B_img + 7) / 8) * 8 * p.n_items;
   if (grid <= 0) return GLR_OK;
   hipStream_t st = (hipStream_t)stream;
+#define GLR_LAUNCH_K1(OP, FULL)                                                                                      \
+  do {                                                                                                               \
+    if (hipFuncSetAttribute((const void*)k_local_attn<OP, BWD, FULL>, hipFuncAttributeMaxDynamicSharedMemorySize,   \
+                            lds) != hipSuccess)                                                                      \
+      return GLR_ELAUNCH;                                                                                            \
+    hipLaunchKernelGGL((k_local_attn<OP, BWD, FULL>), dim3(grid), dim3(NTHR), lds, st, p);                            \
+  } while (0)
+  const bool full = p.S_pad == GLR_MAX_SPAD;
   if (op_dtype == GLR_BF16) {
-    if (hipFuncSetAttribute((const void*)k_local_attn<OpBF16, BWD>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return GLR_ELAUNCH;
-    hipLaunchKernelGGL((k_local_attn<OpBF16, BWD>), dim3(grid), dim3(NTHR), lds, st, p);
+    if (full) GLR_LAUNCH_K1(OpBF16, true); else GLR_LAUNCH_K1(OpBF16, false);
   } else {
-    if (hipFuncSetAttribute((const void*)k_local_attn<OpF32, BWD>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return GLR_ELAUNCH;
-    hipLaunchKernelGGL((k_local_attn<OpF32, BWD>), dim3(grid), dim3(NTHR), lds, st, p);
+    if (full) GLR_LAUNCH_K1(OpF32, true); else GLR_LAUNCH_K1(OpF32, false);
   }
+#undef GLR_LAUNCH_K1
   GLR_CHECK_LAUNCH();
   return GLR_OK;
 }
 
 int launch_pair(LaParams& p, int op_dtype, void* stream) {
   if (op_dtype != GLR_BF16) return GLR_EINVAL;      // the fp32 mode (32-word tiles) is never paired
+  if (p.S_pad != GLR_MAX_SPAD) return GLR_EINVAL;   // the pair kernel is built for the 384-region shape only
   const int lds = carve_pair(p, op_dtype, p.S_pad);
   if (lds > 160 * 1024) return GLR_EINVAL;
   const int grid = ((p.B_img + 7) / 8) * 8 * p.n_items;

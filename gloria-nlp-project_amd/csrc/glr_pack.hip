@@ -65,15 +65,13 @@ extern "C" int glr_plan_items(const int32_t* tile_nsub, const int32_t* tile_firs
                               int32_t* counts) {
   if (!tile_nsub || !tile_first || !single_tile || !pair_tile || !all_tile || !counts || n_tiles <= 0) return GLR_EINVAL;
   int ns = 0, np = 0, na = 0;
-  auto pairable = [&](int t) {
-    return t < n_tiles && tile_nsub[t] == 0 && tile_first[t + 1] - tile_first[t] <= max_pair_seg;
-  };
+  auto pairable = [&](int t) { return t < n_tiles && tile_nsub[t] == 0; };
   for (int t = 0; t < n_tiles;) {
     if (tile_nsub[t] < 0) return GLR_EINVAL;         // a continuation tile cannot start an item
     if (tile_nsub[t] > 1) {                          // multi-tile sentence: one item, handled in sweeps
       single_tile[ns++] = t; all_tile[na++] = t;
       t += tile_nsub[t];
-    } else if (allow_pairs && pairable(t) && pairable(t + 1)) {
+    } else if (allow_pairs && pairable(t) && pairable(t + 1) && tile_first[t + 2] - tile_first[t] <= max_pair_seg) {
       pair_tile[np++] = t; all_tile[na++] = t; all_tile[na++] = t + 1;
       t += 2;
     } else {
@@ -165,7 +163,31 @@ __global__ void __launch_bounds__(256) k_word_norms(const void* __restrict__ tp,
   if (lane == 0) tnorm[slot] = sqrtf(s);
 }
 
+// K-tiling copy: every block of `rows` rows x `row_bytes` bytes is rewritten as [row_bytes / 64][rows][64 B],
+// so that the K1 streams read 1-KiB contiguous pieces.  One thread moves 16 bytes; writes are linear.
+__global__ void k_tile_k(const uint4* __restrict__ src, uint4* __restrict__ dst, int rows, int nch, size_t total) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int s16 = (int)(i & 3);
+  const size_t t = i >> 2;
+  const int r = (int)(t % rows);
+  const size_t u = t / rows;
+  const int c = (int)(u % nch);
+  const size_t blk = u / nch;
+  dst[i] = src[((blk * rows + r) * nch + c) * 4 + s16];
+}
+
 }  // namespace
+
+extern "C" int glr_tile_k(const void* src, void* dst, int rows, long long n_blocks, int row_bytes, void* stream) {
+  if (!src || !dst || rows <= 0 || n_blocks <= 0 || row_bytes <= 0 || row_bytes % 64 != 0) return GLR_EINVAL;
+  const size_t total = (size_t)n_blocks * rows * (row_bytes / 16);
+  const int nch = row_bytes / 64;
+  hipLaunchKernelGGL(k_tile_k, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const uint4*)src, (uint4*)dst, rows, nch, total);
+  GLR_CHECK_LAUNCH();
+  return GLR_OK;
+}
 
 extern "C" int glr_pack_regions(const void* img_features, int in_dtype, int in_layout, const void* no_attn_vec,
                                 void* vt, int B, int D, int S, int op_dtype, void* stream) {

@@ -74,7 +74,7 @@ def _pack_operands(img_features, words, no_attn_vec, cap_lens, o):
         raise ValueError(f"embedding dim must be a multiple of 64, got {D}")
     code = _op_code(img_features, words)
     odt = N.torch_dtype(code)
-    plan = N.TilePlan(cap_lens, dev, L.glr_tile_capacity(code))
+    plan = N.TilePlan(cap_lens, dev, L.glr_tile_capacity(code), allow_pairs=(s_pad == N.MAX_SPAD))
     # channels-last feature maps already are [B, S, D] in memory: no transpose needed
     img = img_features
     layout = 0
@@ -97,7 +97,13 @@ def _pack_operands(img_features, words, no_attn_vec, cap_lens, o):
     N.check(L.glr_pack_words(N.ptr(words), in_code, N.ptr(plan.sent_slot0), N.ptr(plan.cap_lens), N.ptr(tp),
                              N.ptr(tnorm), words.shape[0], D, words.shape[2], o.word_start, plan.n_slots,
                              plan.capacity, code, st), "glr_pack_words")
-    return plan, code, vt, gram, tp, tnorm, s_eff, s_pad, shift
+    # K1 streams the K-tiled copies (contiguous 1-KiB DMA pieces); the row-major vt / tp stay for the gradient GEMMs
+    esz = vt.element_size()
+    vt_t, gram_t, tp_t = torch.empty_like(vt), torch.empty_like(gram), torch.empty_like(tp)
+    N.check(L.glr_tile_k(N.ptr(vt), N.ptr(vt_t), s_pad, B, D * esz, st), "glr_tile_k")
+    N.check(L.glr_tile_k(N.ptr(gram), N.ptr(gram_t), s_pad, B, s_pad * esz, st), "glr_tile_k")
+    N.check(L.glr_tile_k(N.ptr(tp), N.ptr(tp_t), N.TILE_WORDS, plan.n_tiles, D * esz, st), "glr_tile_k")
+    return plan, code, vt, vt_t, gram_t, tp, tp_t, tnorm, s_eff, s_pad, shift
 
 
 def _k1_args(plan, vt, gram, tp, tnorm, B, D, s_eff, o, backward=False):
@@ -125,7 +131,7 @@ class LocalSimFn(torch.autograd.Function):
         img = _as_supported(img_features.detach()) if img_features.dtype not in (torch.float32, torch.bfloat16) \
             else img_features.detach()
         words = _as_supported(words_emb.detach())
-        plan, code, vt, gram, tp, tnorm, s_eff, s_pad, shift = _pack_operands(img, words, no_attn_vec, cap_lens, o)
+        plan, code, vt, vt_t, gram_t, tp, tp_t, tnorm, s_eff, s_pad, shift = _pack_operands(img, words, no_attn_vec, cap_lens, o)
         dev = img.device
         B, D = img.shape[:2]
         n_sent = plan.n_sent
@@ -142,7 +148,7 @@ class LocalSimFn(torch.autograd.Function):
         if K1_EVENTS is not None:
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()
-        N.check(L.glr_local_attn_fwd(*_k1_args(plan, vt, gram, tp, tnorm, B, D, s_eff, o), N.ptr(sim), n_sent,
+        N.check(L.glr_local_attn_fwd(*_k1_args(plan, vt_t, gram_t, tp_t, tnorm, B, D, s_eff, o), N.ptr(sim), n_sent,
                                      N.ptr(lse), N.ptr(wstat), N.ptr(attn), N.ptr(attn_off), strip,
                                      1 if o.pair_only else 0, o.img_offset, code, N.stream()),
                 "glr_local_attn_fwd")
@@ -156,7 +162,7 @@ class LocalSimFn(torch.autograd.Function):
             a2 = attn.view(B, n, s_eff)
             wctx = torch.bmm(a2.to(vt.dtype), vt[:, :s_eff]).transpose(1, 2).float().contiguous()   # [B, D, n]
             attn = a2[:, :, shift:].contiguous().view(-1)
-        ctx.save_for_backward(img_features, words_emb, no_attn_vec, vt, gram, tp, tnorm, sim, lse, wstat)
+        ctx.save_for_backward(img_features, words_emb, no_attn_vec, vt, vt_t, gram_t, tp, tp_t, tnorm, sim, lse, wstat)
         ctx.plan, ctx.opts, ctx.meta = plan, o, (code, s_eff, s_pad, shift)
         ctx.set_materialize_grads(False)       # unused outputs (maps, context) arrive as None
         if attn is None:
@@ -167,7 +173,7 @@ class LocalSimFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dsim, dattn, dwctx):
-        img_features, words_emb, no_attn_vec, vt, gram, tp, tnorm, sim, lse, wstat = ctx.saved_tensors
+        img_features, words_emb, no_attn_vec, vt, vt_t, gram_t, tp, tp_t, tnorm, sim, lse, wstat = ctx.saved_tensors
         plan, o = ctx.plan, ctx.opts
         code, s_eff, s_pad, shift = ctx.meta
         L = N.lib()
@@ -187,7 +193,7 @@ class LocalSimFn(torch.autograd.Function):
             gamma = torch.empty(B, ns, dtype=torch.float32, device=dev)
             beta = torch.empty(B, ns, dtype=torch.float32, device=dev)
             g = dsim.float().contiguous()
-            N.check(L.glr_local_attn_bwd(*_k1_args(plan, vt, gram, tp, tnorm, B, D, s_eff, o, True), N.ptr(sim), N.ptr(g),
+            N.check(L.glr_local_attn_bwd(*_k1_args(plan, vt_t, gram_t, tp_t, tnorm, B, D, s_eff, o, True), N.ptr(sim), N.ptr(g),
                                          plan.n_sent, N.ptr(lse), N.ptr(wstat), N.ptr(xout), N.ptr(aout),
                                          N.ptr(gamma), N.ptr(beta), code, N.stream()), "glr_local_attn_bwd")
             # gradient GEMMs (plain library GEMMs on the kernel's outputs)

@@ -79,7 +79,7 @@ int glr_plan_tiles(const int32_t* cap_lens, int n_sent, int capacity, int32_t* s
                    int32_t* tile_first, int32_t* order, int32_t* tile_nsub);
 
 /* Work items of the local-attention kernels.  With allow_pairs, two consecutive ordinary tiles that hold
- * at most max_pair_seg (16) sentences each become ONE forward work item: a workgroup then streams vt[b] and
+ * at most max_pair_seg (16) sentences IN TOTAL become ONE forward work item: a workgroup then streams vt[b] and
  * gram[b] once for 128 words (the streams are the bound).  Outputs (each must hold n_tiles ints):
  *   single_tile  first tile of every un-paired item (ordinary tile or head of a multi-tile sentence)
  *   pair_tile    first tile of every pair
@@ -125,8 +125,8 @@ int glr_pack_words(const void* words_emb, int in_dtype, const int32_t* sent_slot
  *
  * One workgroup per (image b, word tile); kernel anatomy in DESIGN.md.
  *
- *   vt, gram     packed regions of the B_img LOCAL images and their Gram matrices
- *   tp, tnorm    packed words of ALL sentences (glr_pack_words)
+ *   vt, gram     packed regions of the B_img LOCAL images and their Gram matrices, K-TILED (glr_tile_k, rows = S_pad)
+ *   tp, tnorm    packed words of ALL sentences (glr_pack_words); tp K-TILED (glr_tile_k, rows = 64)
  *   sent_slot0, cap_lens   [n_sent] device int32 (same arrays as given to glr_pack_words)
  *   tile_first, order, tile_nsub   device int32 copies of the glr_plan_tiles outputs
  *   single_tile/n_single, pair_tile/n_pair (fwd), item_tile/n_items (bwd: the all_tile list)
@@ -166,6 +166,14 @@ int glr_local_attn_bwd(const void* vt, const void* gram, const void* tp, const f
                        int agg, float eps, const float* sim, const float* dsim, int ld_sim, const float* lse,
                        const float* wstat, void* xout, void* aout, float* gamma, float* beta, int op_dtype,
                        void* stream);
+
+/* K-tiling of the K1 operands (device, HBM-bound copy).  glr_local_attn_fwd / _bwd take vt, gram and tp in
+ * the K-TILED layout: every block of `rows` rows (vt, gram: the S_pad rows of one image; tp: the 64 slots of one
+ * tile) is stored as [row_bytes / 64][rows][64 bytes], i.e. the 64-byte K chunks of all rows of a block are
+ * contiguous, which turns every LDS-DMA piece of the K1 streams into one contiguous 1-KiB read.
+ *   src   row-major [n_blocks * rows][row_bytes]     dst  same size, tiled     row_bytes % 64 == 0
+ */
+int glr_tile_k(const void* src, void* dst, int rows, long long n_blocks, int row_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * K2  dual cross-entropy on a square similarity matrix (labels = arange).

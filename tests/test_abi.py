@@ -72,7 +72,7 @@ def test_plan_items_pairing():
     covered = []
     for t in pairs:
         assert nsub[t] == 0 and nsub[t + 1] == 0
-        assert tf[t + 1] - tf[t] <= 16 and tf[t + 2] - tf[t + 1] <= 16     # pair tiles hold <= 16 sentences
+        assert tf[t + 2] - tf[t] <= 16                                         # a pair holds <= 16 sentences
         covered += [t, t + 1]
     for t in singles:
         covered += list(range(t, t + max(nsub[t], 1)))

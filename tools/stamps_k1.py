@@ -33,10 +33,10 @@ if not bwd:
     s2 = buf2.cpu().numpy().reshape(grid, 12)
     s2 = s2[s2[:, 0] > 0]
     if len(s2):
-        n2 = ["setup (plan loads, tables)", "P1 gemm (128 words)", "walk A", "walk B", "P2 A", "P2 B", "P3 gemm (128 words)",
-              "P4 A", "P4 B"]
-        d2 = np.diff(s2[:, :10].astype(np.float64), axis=1)
-        t2 = (s2[:, 9] - s2[:, 0]).astype(np.float64)
+        n2 = ["setup (plan loads, tables)", "P1 gemm (128 words)", "table init + run max", "run sum + lse", "P2 A+B",
+              "P3 gemm (128 words)", "P4 region sums", "P4 cosine/aggregate/maps"]
+        d2 = np.diff(s2[:, :9].astype(np.float64), axis=1)
+        t2 = (s2[:, 8] - s2[:, 0]).astype(np.float64)
         print(f"fwd PAIR kernel: workgroups {len(s2)}, median cycles per pair {np.median(t2):.0f}")
         for i, n in enumerate(n2):
             print(f"  {n:28s} median {np.median(d2[:, i]):9.0f}  share {np.median(d2[:, i]) / np.median(t2) * 100:5.1f}%")
