@@ -167,7 +167,173 @@ __global__ void __launch_bounds__(256) k_cosine_bwd(const float* __restrict__ x1
   }
 }
 
+// ------------------------------------------------------------------ K6: attention regularisers
+// Inputs: amean[b, i, r] = word-mean attention of image b for sentence i (K1 forward).  With a no-attention
+// column (shift = 1) the reference works on P = [1 - sum_{r>=1} A[r], A[1:]] (gloria_loss.py:131-135), else P = A.
+//   entropy[b, i] = -sum_r P log P                               (:95-96, :136-137)
+//   kl[b, i]      = 1/2 sum_r (P_d - P_i)(log P_d - log P_i),  d = img_offset + b   (:91-92, :180-190)
+//   na[b]         = log(1 - sum_{r>=shift} A_d[r])               (:130)
+// One workgroup (4 waves) per image; wave w takes sentences w, w+4, ...; a row is 6 values per lane.
+constexpr int REG_K = GLR_MAX_SPAD / 64;
+
+struct RegRow { float p[REG_K], lp[REG_K]; };
+
+__device__ __forceinline__ void reg_load_row(const float* __restrict__ a, int S_eff, int shift, int lane, RegRow& row) {
+  float rest = 0.f;
+#pragma unroll
+  for (int k = 0; k < REG_K; ++k) {
+    const int r = lane + 64 * k;
+    row.p[k] = (r < S_eff) ? a[r] : 0.f;
+    if (r >= 1) rest += row.p[k];
+  }
+  if (shift) {
+    rest = wave_sum(rest);
+    if (lane == 0) row.p[0] = 1.f - rest;
+  }
+#pragma unroll
+  for (int k = 0; k < REG_K; ++k) row.lp[k] = (lane + 64 * k < S_eff) ? __logf(row.p[k]) : 0.f;
+}
+
+__global__ void __launch_bounds__(256) k_attn_reg_fwd(const float* __restrict__ amean, int n_sent, int S_pad, int S_eff,
+                                                      int shift, int img_offset, float* __restrict__ out) {
+  __shared__ float red[4][2];
+  const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int d = img_offset + b;
+  const float* base = amean + (size_t)b * n_sent * S_pad;
+  RegRow pd;
+  reg_load_row(base + (size_t)d * S_pad, S_eff, shift, lane, pd);
+  float ent = 0.f, kl = 0.f;
+  for (int i = wave; i < n_sent; i += 4) {
+    RegRow pi;
+    reg_load_row(base + (size_t)i * S_pad, S_eff, shift, lane, pi);
+    float e = 0.f, k2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < REG_K; ++k) {
+      if (lane + 64 * k < S_eff) {
+        e -= pi.p[k] * pi.lp[k];
+        k2 += (pd.p[k] - pi.p[k]) * (pd.lp[k] - pi.lp[k]);
+      }
+    }
+    ent += wave_sum(e);
+    if (i != d) kl += 0.5f * wave_sum(k2);
+  }
+  if (lane == 0) { red[wave][0] = ent; red[wave][1] = kl; }
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    // no-attention score of the diagonal pair: log(1 - mean_w sum_{r >= shift} a2)
+    float sa = 0.f;
+#pragma unroll
+    for (int k = 0; k < REG_K; ++k) {
+      const int r = lane + 64 * k;
+      if (r >= shift && r < S_eff) sa += base[(size_t)d * S_pad + r];
+    }
+    sa = wave_sum(sa);
+    if (lane == 0) {
+      out[b * 4 + 0] = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]);
+      out[b * 4 + 1] = (red[0][1] + red[1][1]) + (red[2][1] + red[3][1]);
+      out[b * 4 + 2] = __logf(1.f - sa);
+      out[b * 4 + 3] = 0.f;
+    }
+  }
+}
+
+// gradient w.r.t. amean of  coef[0] * sum entropy + coef[1] * sum kl + coef[2] * sum na
+__global__ void __launch_bounds__(256) k_attn_reg_bwd(const float* __restrict__ amean, int n_sent, int S_pad, int S_eff,
+                                                      int shift, int img_offset, const float* __restrict__ coef,
+                                                      float* __restrict__ damean) {
+  __shared__ float dacc[4][GLR_MAX_SPAD];
+  const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int d = img_offset + b;
+  const float ce = coef[0], ck = coef[1], cn = coef[2];
+  const float* base = amean + (size_t)b * n_sent * S_pad;
+  float* dbase = damean + (size_t)b * n_sent * S_pad;
+  RegRow pd;
+  reg_load_row(base + (size_t)d * S_pad, S_eff, shift, lane, pd);
+  float dd[REG_K];                                    // this wave's share of d kl / d P_d
+#pragma unroll
+  for (int k = 0; k < REG_K; ++k) dd[k] = 0.f;
+  for (int i = wave; i < n_sent; i += 4) {
+    if (i == d) continue;
+    RegRow pi;
+    reg_load_row(base + (size_t)i * S_pad, S_eff, shift, lane, pi);
+    float dp[REG_K];
+#pragma unroll
+    for (int k = 0; k < REG_K; ++k) {
+      dp[k] = 0.f;
+      if (lane + 64 * k < S_eff) {
+        const float dl = pi.lp[k] - pd.lp[k];          // log P_i - log P_d
+        dp[k] = -ce * (pi.lp[k] + 1.f) + 0.5f * ck * (dl - pd.p[k] / pi.p[k] + 1.f);
+        dd[k] += 0.5f * ck * (-dl + 1.f - pi.p[k] / pd.p[k]);
+      }
+    }
+    const float dp0 = __shfl(dp[0], 0, 64);            // d / d P[0] (the "1 - rest" entry when shift)
+#pragma unroll
+    for (int k = 0; k < REG_K; ++k) {
+      const int r = lane + 64 * k;
+      float v = 0.f;
+      if (r < S_eff) v = shift ? (r >= 1 ? dp[k] - dp0 : 0.f) : dp[k];
+      if (r < S_pad) dbase[(size_t)i * S_pad + r] = v;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < REG_K; ++k) dacc[wave][lane + 64 * k] = dd[k];
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    // diagonal row: entropy term + the kl terms of all other sentences (fixed wave order) + no-attention term
+    float sa = 0.f;
+#pragma unroll
+    for (int k = 0; k < REG_K; ++k) {
+      const int r = lane + 64 * k;
+      if (r >= shift && r < S_eff) sa += base[(size_t)d * S_pad + r];
+    }
+    sa = wave_sum(sa);
+    const float dna = cn != 0.f ? -cn / (1.f - sa) : 0.f;   // d na / d A_d[r], r >= shift (1 - sa ~ 0 without the extra column)
+    float dp[REG_K];
+#pragma unroll
+    for (int k = 0; k < REG_K; ++k) {
+      const int r = lane + 64 * k;
+      dp[k] = 0.f;
+      if (r < S_eff)
+        dp[k] = -ce * (pd.lp[k] + 1.f) + ((dacc[0][r] + dacc[1][r]) + (dacc[2][r] + dacc[3][r]));
+    }
+    const float dp0 = __shfl(dp[0], 0, 64);
+#pragma unroll
+    for (int k = 0; k < REG_K; ++k) {
+      const int r = lane + 64 * k;
+      float v = 0.f;
+      if (r < S_eff) {
+        v = shift ? (r >= 1 ? dp[k] - dp0 : 0.f) : dp[k];
+        if (r >= shift) v += dna;
+      }
+      if (r < S_pad) dbase[(size_t)d * S_pad + r] = v;
+    }
+  }
+}
+
 }  // namespace
+
+extern "C" int glr_attn_reg_fwd(const float* amean, int B_img, int n_sent, int S_pad, int S_eff, int shift,
+                                int img_offset, float* out, void* stream) {
+  if (!amean || !out || B_img <= 0 || n_sent <= 0 || S_pad <= 0 || S_pad > GLR_MAX_SPAD || S_pad % 64 != 0) return GLR_EINVAL;
+  if (S_eff <= shift || S_eff > S_pad || (shift != 0 && shift != 1) || img_offset < 0 || img_offset + B_img > n_sent)
+    return GLR_EINVAL;
+  hipLaunchKernelGGL(k_attn_reg_fwd, dim3(B_img), dim3(256), 0, (hipStream_t)stream, amean, n_sent, S_pad, S_eff, shift,
+                     img_offset, out);
+  GLR_CHECK_LAUNCH();
+  return GLR_OK;
+}
+
+extern "C" int glr_attn_reg_bwd(const float* amean, int B_img, int n_sent, int S_pad, int S_eff, int shift,
+                                int img_offset, const float* coef, float* damean, void* stream) {
+  if (!amean || !coef || !damean || B_img <= 0 || n_sent <= 0 || S_pad <= 0 || S_pad > GLR_MAX_SPAD || S_pad % 64 != 0)
+    return GLR_EINVAL;
+  if (S_eff <= shift || S_eff > S_pad || (shift != 0 && shift != 1) || img_offset < 0 || img_offset + B_img > n_sent)
+    return GLR_EINVAL;
+  hipLaunchKernelGGL(k_attn_reg_bwd, dim3(B_img), dim3(256), 0, (hipStream_t)stream, amean, n_sent, S_pad, S_eff, shift,
+                     img_offset, coef, damean);
+  GLR_CHECK_LAUNCH();
+  return GLR_OK;
+}
 
 extern "C" int glr_wordpiece_segsum_fwd(const void* const* hidden, int n_layers, int in_dtype, const int32_t* dst,
                                         float* word_emb, float* sent_emb, int B, int L, int D, int mean_layers,

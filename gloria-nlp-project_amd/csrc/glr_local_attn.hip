@@ -71,6 +71,8 @@ struct LaParams {
   float* lse;                   // [B_img][n_sent][S_pad]  (fwd: optional out, bwd: in)
   float* wstat;                 // [B_img][n_slots][WSTAT] (fwd: optional out, bwd: in)
   float* attn;                  // fwd optional out
+  float* amean;                 // fwd optional out: [B_img][n_sent][S_pad] word-mean attention row of every pair
+  const float* damean;          // bwd optional in:  gradient w.r.t. amean
   const long long* attn_off;
   int strip;
   int pair_only, img_offset;
@@ -498,6 +500,7 @@ __global__ void __launch_bounds__(NTHR) k_local_attn(LaParams p) {
       // log-sum-exp is (re)loaded only when the run changes
       int cur = -2;
       float lcur[3] = {0.f, 0.f, 0.f};
+      float gcur[3] = {0.f, 0.f, 0.f};     // bwd: gradient of the word-mean attention row / words in the sentence
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         const int word = wm * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
@@ -507,11 +510,16 @@ __global__ void __launch_bounds__(NTHR) k_local_attn(LaParams p) {
         if (sg != cur && sg >= 0) {
           cur = sg;
           const int sent = seg_sent[sg];
+          const float ninv = 1.f / (float)(nsub > 1 ? long_n : seg_n[sg]);
 #pragma unroll
           for (int j = 0; j < 3; ++j) {
             const int region = min((wg + 4 * j) * 32 + l31, S_pad - 1);
-            if (BWD) lcur[j] = p.lse[((size_t)b * p.n_sent + sent) * S_pad + region];
-            else lcur[j] = (nsub > 1) ? mrun[region] : sc[sg * SCP + region];
+            if (BWD) {
+              lcur[j] = p.lse[((size_t)b * p.n_sent + sent) * S_pad + region];
+              if (p.damean != nullptr) gcur[j] = p.damean[((size_t)b * p.n_sent + sent) * S_pad + region] * ninv;
+            } else {
+              lcur[j] = (nsub > 1) ? mrun[region] : sc[sg * SCP + region];
+            }
           }
         }
         float zacc = 0.f, dacc = 0.f;
@@ -525,9 +533,12 @@ __global__ void __launch_bounds__(NTHR) k_local_attn(LaParams p) {
             const float a1 = ok ? __expf(acc[j][q] - lcur[j]) : 0.f;
             const float e2 = ok ? __expf(p.temp1 * a1) : 0.f;
             if (BWD) {
-              O::from_f32(img + word * IMP + region * ESZ, be * (e2 * zi));
+              // da2 = (alpha s - beta u) + g: the accumulator starts at -(alpha s + g), P3 adds beta u
+              const float a2 = e2 * zi;
+              O::from_f32(img + word * IMP + region * ESZ, be * a2);
               a1r[j][q] = a1;
-              acc[j][q] = -al * acc[j][q];
+              acc[j][q] = -al * acc[j][q] - (ok ? gcur[j] : 0.f);
+              zacc += a2 * gcur[j];              // kappa gains sum_r a2 g  (softmax-over-regions backward)
             } else {
               O::from_f32(img + word * IMP + region * ESZ, e2);
               const float e2r = ESZ == 4 ? e2 : bf2f(f2bf(e2));        // as the MFMA will see it
@@ -553,8 +564,24 @@ __global__ void __launch_bounds__(NTHR) k_local_attn(LaParams p) {
           red[(1 * 8 + rslot) * TW + word] = d;
         }
       }
+    } else if (p.damean != nullptr) {
+      const int rslot = wg * 2 + ((lane >> 4) & 1);
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const float z = row_sum16(zq[q]);
+        if ((lane & 15) == 15 && wactive) {
+          const int word = wm * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+          red[(1 * 8 + rslot) * TW + word] = z;          // rows 8..15 of red: free in the backward kernel
+        }
+      }
     }
     __syncthreads();        // image complete (and the score tile is dead: the ring may be reused)
+    if (BWD && p.damean != nullptr && tid < TW) {
+      float kg = 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) kg += red[(8 + k) * TW + tid];
+      w_ka[tid] += kg;      // read by P4 behind the barriers of the P3 stream
+    }
 
     GLR_STAMP(3);
     // ================= P3: acc[w, r] (+)= image . G^T =================
@@ -604,6 +631,25 @@ __global__ void __launch_bounds__(NTHR) k_local_attn(LaParams p) {
         }
       }
       __syncthreads();
+      if (p.amean != nullptr && tid < S_pad) {
+        // word-mean attention row A[r] = mean_w a2[w, r] of every sentence of the tile (aux regularisers,
+        // gloria_loss.py:131-139); a multi-tile sentence accumulates across its sub-tiles in srun
+        const int r = tid;
+        for (int s = 0; s < nseg; ++s) {
+          const int w0 = seg_w0[s], n = seg_n[s];
+          float a = 0.f;
+          for (int w = 0; w < n; ++w) a += O::to_f32(img + (w0 + w) * IMP + r * ESZ) / zsum[w0 + w];
+          int ntot = n;
+          bool emit = true;
+          if (nsub > 1) {
+            if (sub > 0) a += srun[r];
+            srun[r] = a;
+            emit = (sub == nsub - 1);
+            ntot = long_n;
+          }
+          if (emit) p.amean[((size_t)b * p.n_sent + seg_sent[s]) * S_pad + r] = r < p.S_eff ? a / (float)ntot : 0.f;
+        }
+      }
       if (tid < nseg) {
         const int w0 = seg_w0[tid], n = seg_n[tid];
         float v = 0.f;
@@ -1056,6 +1102,18 @@ __global__ void __launch_bounds__(NTHR) k_local_attn_pair(LaParams p) {
       out[idx] = O::to_f32(img + (dwl + w) * IMP + r * ESZ) / zsum[dw0 + w];
     }
   }
+  if (p.amean != nullptr && tid < SP) {
+    // word-mean attention row A[r] = mean_w a2[w, r] of every sentence of the pair (aux regularisers,
+    // gloria_loss.py:131-139), from the e2 images and the per-word Z
+    const int r = tid;
+    for (int s2 = 0; s2 < NS; ++s2) {
+      const int w0 = seg_w0[s2], n = seg_n[s2];
+      const unsigned char* col = img0 + (w0 >> 6) * IMG + (w0 & 63) * IMP + r * ESZ;
+      float a = 0.f;
+      for (int w = 0; w < n; ++w) a += O::to_f32(col + w * IMP) / zsum[w0 + w];
+      p.amean[((size_t)b * p.n_sent + seg_sent[s2]) * SP + r] = r < p.S_eff ? a / (float)n : 0.f;
+    }
+  }
   GLR_STAMP2(8);
 #undef GLR_SGQ
 }
@@ -1138,7 +1196,7 @@ int fill_common(LaParams& p, const void* vt, const void* gram, const void* tp, c
   if (agg < 0 || agg > 2) return GLR_EINVAL;
   p.vt = (const unsigned char*)vt; p.gram = (const unsigned char*)gram; p.tp = (const unsigned char*)tp;
   p.tnorm = tnorm; p.sent_slot0 = sent_slot0; p.cap_lens = cap_lens; p.tile_first = tile_first; p.order = order;
-  p.tile_nsub = tile_nsub; p.item_tile = nullptr; p.n_items = 0; p.n_tiles = n_tiles; p.n_sent = n_sent;
+  p.tile_nsub = tile_nsub; p.item_tile = nullptr; p.n_items = 0; p.amean = nullptr; p.damean = nullptr; p.n_tiles = n_tiles; p.n_sent = n_sent;
   p.n_slots = n_tiles * TW; p.B_img = B_img;
   p.D = D; p.S_eff = S_eff; p.S_pad = S_pad; p.temp1 = temp1; p.temp2 = temp2; p.temp3 = temp3; p.agg = agg;
   p.eps = eps;
@@ -1162,7 +1220,7 @@ extern "C" int glr_local_attn_fwd(const void* vt, const void* gram, const void* 
                                   int n_tiles, int n_sent, int B_img, int D, int S_eff, float temp1, float temp2,
                                   float temp3, int agg, float eps, float* sim, int ld_sim, float* lse, float* wstat,
                                   float* attn, const int64_t* attn_off, int strip, int pair_only, int img_offset,
-                                  int op_dtype, void* stream) {
+                                  float* amean, int op_dtype, void* stream) {
   LaParams p;
   int rc = fill_common(p, vt, gram, tp, tnorm, sent_slot0, cap_lens, tile_first, order, tile_nsub, n_tiles,
                        n_sent, B_img, D, S_eff, temp1, temp2, temp3, agg, eps, op_dtype);
@@ -1171,7 +1229,8 @@ extern "C" int glr_local_attn_fwd(const void* vt, const void* gram, const void* 
   if (n_single < 0 || n_pair < 0 || (n_single > 0 && !single_tile) || (n_pair > 0 && !pair_tile)) return GLR_EINVAL;
   if (pair_only && img_offset + B_img > n_sent) return GLR_EINVAL;
   if (!pair_only && n_single + n_pair == 0) return GLR_EINVAL;
-  p.sim = sim; p.ld_sim = ld_sim; p.lse = lse; p.wstat = wstat; p.attn = attn;
+  if (amean && pair_only) return GLR_EINVAL;
+  p.sim = sim; p.ld_sim = ld_sim; p.lse = lse; p.wstat = wstat; p.attn = attn; p.amean = amean;
   p.attn_off = (const long long*)attn_off; p.strip = strip; p.pair_only = pair_only; p.img_offset = img_offset;
   if (pair_only || n_single > 0) {
     p.item_tile = single_tile; p.n_items = n_single;
@@ -1191,8 +1250,8 @@ extern "C" int glr_local_attn_bwd(const void* vt, const void* gram, const void* 
                                   const int32_t* item_tile, int n_items, int n_tiles, int n_sent, int B_img, int D,
                                   int S_eff, float temp1, float temp2, float temp3, int agg, float eps,
                                   const float* sim, const float* dsim, int ld_sim, const float* lse,
-                                  const float* wstat, void* xout, void* aout, float* gamma, float* beta,
-                                  int op_dtype, void* stream) {
+                                  const float* wstat, const float* damean, void* xout, void* aout, float* gamma,
+                                  float* beta, int op_dtype, void* stream) {
   LaParams p;
   const int rc = fill_common(p, vt, gram, tp, tnorm, sent_slot0, cap_lens, tile_first, order, tile_nsub, n_tiles,
                              n_sent, B_img, D, S_eff, temp1, temp2, temp3, agg, eps, op_dtype);
@@ -1201,7 +1260,7 @@ extern "C" int glr_local_attn_bwd(const void* vt, const void* gram, const void* 
   if (agg == GLR_AGG_MAX) return GLR_EINVAL;      // max aggregation is inference-only (gloria_model.py:199)
   p.sim = const_cast<float*>(sim); p.dsim = dsim; p.ld_sim = ld_sim; p.lse = const_cast<float*>(lse);
   p.wstat = const_cast<float*>(wstat); p.xout = (unsigned char*)xout; p.aout = (unsigned char*)aout;
-  p.gamma = gamma; p.beta = beta; p.item_tile = item_tile; p.n_items = n_items;
+  p.gamma = gamma; p.beta = beta; p.item_tile = item_tile; p.n_items = n_items; p.damean = damean;
   return launch<true>(p, op_dtype, stream);
 }
 

@@ -32,10 +32,13 @@ SYMBOLS = {
     "glr_pack_words": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                c_int, c_int, c_int, c_void_p]),
     "glr_local_attn_fwd": (c_int, [c_void_p] * 10 + [c_int, c_void_p] + [c_int] * 6 + [c_float] * 3 + [c_int, c_float, c_void_p, c_int,
-                                   c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+                                   c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
+                                   # ..., sim, ld, lse, wstat, attn, attn_off, strip, pair_only, img_offset, amean, dtype, stream
     "glr_local_attn_bwd": (c_int, [c_void_p] * 10 + [c_int] * 6 + [c_float] * 3 + [c_int, c_float, c_void_p, c_void_p,
-                                   c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
-                                   c_void_p]),      # sim, dsim, ld, lse, wstat, xout, aout, gamma, beta, dtype, stream
+                                   c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                   c_void_p]),      # sim, dsim, ld, lse, wstat, damean, xout, aout, gamma, beta, dtype, stream
+    "glr_attn_reg_fwd": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "glr_attn_reg_bwd": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "glr_dual_ce_fwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "glr_dual_ce_bwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "glr_global_sim_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float, c_void_p, c_int,

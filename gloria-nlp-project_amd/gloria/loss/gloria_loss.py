@@ -52,11 +52,12 @@ def _as_supported(t):
 # ------------------------------------------------------------------------------------------
 
 class _Opts:
-    def __init__(self, temp1, temp2, temp3, agg, eps, want_attn, img_offset, word_start, pair_only, want_wctx):
+    def __init__(self, temp1, temp2, temp3, agg, eps, want_attn, img_offset, word_start, pair_only, want_wctx,
+                 want_amean=False):
         self.temp1, self.temp2, self.temp3 = float(temp1), float(temp2), float(temp3)
         self.agg, self.eps = agg, float(eps)
         self.want_attn, self.img_offset, self.word_start = want_attn, int(img_offset), int(word_start)
-        self.pair_only, self.want_wctx = pair_only, want_wctx
+        self.pair_only, self.want_wctx, self.want_amean = pair_only, want_wctx, want_amean
 
 
 def _pack_operands(img_features, words, no_attn_vec, cap_lens, o):
@@ -148,9 +149,10 @@ class LocalSimFn(torch.autograd.Function):
         if K1_EVENTS is not None:
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()
+        amean = torch.empty(B, n_sent, s_pad, dtype=torch.float32, device=dev) if o.want_amean else None
         N.check(L.glr_local_attn_fwd(*_k1_args(plan, vt_t, gram_t, tp_t, tnorm, B, D, s_eff, o), N.ptr(sim), n_sent,
                                      N.ptr(lse), N.ptr(wstat), N.ptr(attn), N.ptr(attn_off), strip,
-                                     1 if o.pair_only else 0, o.img_offset, code, N.stream()),
+                                     1 if o.pair_only else 0, o.img_offset, N.ptr(amean), code, N.stream()),
                 "glr_local_attn_fwd")
         if K1_EVENTS is not None:
             ev1.record()
@@ -169,10 +171,12 @@ class LocalSimFn(torch.autograd.Function):
             attn = sim.new_zeros(0)
         if wctx is None:
             wctx = sim.new_zeros(0)
-        return sim, attn, wctx
+        if amean is None:
+            amean = sim.new_zeros(0)
+        return sim, attn, wctx, amean
 
     @staticmethod
-    def backward(ctx, dsim, dattn, dwctx):
+    def backward(ctx, dsim, dattn, dwctx, damean):
         img_features, words_emb, no_attn_vec, vt, vt_t, gram_t, tp, tp_t, tnorm, sim, lse, wstat = ctx.saved_tensors
         plan, o = ctx.plan, ctx.opts
         code, s_eff, s_pad, shift = ctx.meta
@@ -183,9 +187,13 @@ class LocalSimFn(torch.autograd.Function):
         d_words = torch.zeros(words_emb.shape, dtype=torch.float32, device=dev)
         d_na = None if no_attn_vec is None else torch.zeros(D, dtype=torch.float32, device=dev)
 
-        if dsim is not None and not o.pair_only:
+        have_dam = o.want_amean and damean is not None and damean.numel() > 0
+        if (dsim is not None or have_dam) and not o.pair_only:
             if lse is None:
                 raise RuntimeError("local similarity was computed without gradient state")
+            if dsim is None:
+                dsim = torch.zeros_like(sim)
+            dam = damean.float().contiguous() if have_dam else None
             odt = vt.dtype
             ns = plan.n_slots
             xout = torch.empty(ns, B, s_pad, dtype=odt, device=dev)
@@ -194,7 +202,7 @@ class LocalSimFn(torch.autograd.Function):
             beta = torch.empty(B, ns, dtype=torch.float32, device=dev)
             g = dsim.float().contiguous()
             N.check(L.glr_local_attn_bwd(*_k1_args(plan, vt_t, gram_t, tp_t, tnorm, B, D, s_eff, o, True), N.ptr(sim), N.ptr(g),
-                                         plan.n_sent, N.ptr(lse), N.ptr(wstat), N.ptr(xout), N.ptr(aout),
+                                         plan.n_sent, N.ptr(lse), N.ptr(wstat), N.ptr(dam), N.ptr(xout), N.ptr(aout),
                                          N.ptr(gamma), N.ptr(beta), code, N.stream()), "glr_local_attn_bwd")
             # gradient GEMMs (plain library GEMMs on the kernel's outputs)
             x2d = xout.view(ns, B * s_pad)
@@ -363,7 +371,7 @@ def attention_fn(query, context, temp1, no_attn_vec=None):
     B, D, n = query.shape
     ih, iw = context.size(2), context.size(3)
     opts = _Opts(temp1, 1.0, 1.0, "sum", 1e-8, True, 0, 0, True, True)
-    _, attn, wctx = LocalSimFn.apply(context, query, no_attn_vec, [n] * B, opts)
+    _, attn, wctx, _ = LocalSimFn.apply(context, query, no_attn_vec, [n] * B, opts)
     return wctx[:, :, :n].to(query.dtype), attn.view(B, n, ih, iw).to(query.dtype)
 
 
@@ -376,11 +384,55 @@ def global_loss(cnn_code, rnn_code, eps=1e-8, temp3=10.0):
 
 
 def local_similarity(img_features, words_emb, cap_lens: Sequence[int], temp1=4.0, temp2=5.0, temp3=10.0,
-                     agg="sum", no_attn_vec=None, eps=1e-8, want_attn=True, img_offset=0, word_start=0):
-    """B_img x n_sent similarity matrix (already * temp3) + flat diagonal attention maps."""
-    opts = _Opts(temp1, temp2, temp3, agg, eps, want_attn, img_offset, word_start, False, False)
-    sim, attn, _ = LocalSimFn.apply(img_features, words_emb, no_attn_vec, [int(c) for c in cap_lens], opts)
-    return sim, attn, None
+                     agg="sum", no_attn_vec=None, eps=1e-8, want_attn=True, img_offset=0, word_start=0,
+                     want_amean=False):
+    """B_img x n_sent similarity matrix (already * temp3) + flat diagonal attention maps
+    (+ with want_amean the word-mean attention rows [B_img, n_sent, S_pad] of ALL pairs, else None)."""
+    opts = _Opts(temp1, temp2, temp3, agg, eps, want_attn, img_offset, word_start, False, False, want_amean)
+    sim, attn, _, amean = LocalSimFn.apply(img_features, words_emb, no_attn_vec, [int(c) for c in cap_lens], opts)
+    return sim, attn, (amean if want_amean else None)
+
+
+class AttnRegFn(torch.autograd.Function):
+    """Per-image sums of the attention regularisers (K6): out[b] = (sum_i entropy, sum_{i != d} sym-KL, no-attn score)."""
+
+    @staticmethod
+    def forward(ctx, amean, s_eff, shift, img_offset):
+        N.require_cuda(amean)
+        a = amean.detach().float().contiguous()
+        B, n_sent, s_pad = a.shape
+        out = torch.empty(B, 4, dtype=torch.float32, device=a.device)
+        N.check(N.lib().glr_attn_reg_fwd(N.ptr(a), B, n_sent, s_pad, int(s_eff), int(shift), int(img_offset), N.ptr(out),
+                                         N.stream()), "glr_attn_reg_fwd")
+        ctx.save_for_backward(a)
+        ctx.meta = (int(s_eff), int(shift), int(img_offset))
+        return out[:, 0].sum(), out[:, 1].sum(), out[:, 2].sum()
+
+    @staticmethod
+    def backward(ctx, g_ent, g_kl, g_na):
+        (a,) = ctx.saved_tensors
+        s_eff, shift, img_offset = ctx.meta
+        B, n_sent, s_pad = a.shape
+        z = a.new_zeros(())
+        coef = torch.stack([g if g is not None else z for g in (g_ent, g_kl, g_na)]).float().contiguous()
+        dam = torch.empty_like(a)
+        N.check(N.lib().glr_attn_reg_bwd(N.ptr(a), B, n_sent, s_pad, s_eff, shift, img_offset, N.ptr(coef), N.ptr(dam),
+                                         N.stream()), "glr_attn_reg_bwd")
+        return dam, None, None, None
+
+
+def attention_regularisers(amean, s_eff, shift, img_offset, no_attn_loss_weight, attention_divergence_loss_weight,
+                           attention_entropy_loss_weight):
+    """(no_attn_loss, kl_loss, entropy_loss) of ref :172-199 from the word-mean attention rows of this
+    process's images against ALL n_sent sentences.  The means run over the GLOBAL batch (n_sent), so the values
+    of data-parallel ranks add up to the single-process value."""
+    n = amean.shape[1]
+    ent_sum, kl_sum, na_sum = AttnRegFn.apply(amean, s_eff, shift, img_offset)
+    no_attn_loss = no_attn_loss_weight * (na_sum / n) if no_attn_loss_weight is not None else 0            # :173-177
+    kl_loss = attention_divergence_loss_weight * (-(kl_sum / (n * (n - 1)))) \
+        if attention_divergence_loss_weight is not None else 0                                              # :180-192
+    entropy_loss = ent_sum / (n * n) if attention_entropy_loss_weight is not None else 0                  # :195-197 (weight unused)
+    return no_attn_loss, kl_loss, entropy_loss
 
 
 class AttentionMaps(list):
@@ -447,14 +499,18 @@ def local_loss(
 ):
     """Local region x word InfoNCE (ref :99-201).  Returns
     (loss0, loss1, no_attn_loss, kl_loss, entropy_loss, att_maps)."""
-    if (no_attn_loss_weight is not None or attention_divergence_loss_weight is not None
-            or attention_entropy_loss_weight is not None):
-        raise NotImplementedError(
-            "attention regularisers (no_attn / divergence / entropy weights, ref :108-114,172-199) are not "
-            "built yet in the MI355X path (SURVEY.md 8f-1)")
+    want_aux = (no_attn_loss_weight is not None or attention_divergence_loss_weight is not None
+                or attention_entropy_loss_weight is not None)
     ih, iw = img_features.shape[2], img_features.shape[3]
     cap_lens = [int(c) for c in cap_lens]
-    sim, attn, _ = local_similarity(img_features, words_emb, cap_lens, temp1, temp2, temp3, agg, no_attn_vec)
+    sim, attn, amean = local_similarity(img_features, words_emb, cap_lens, temp1, temp2, temp3, agg, no_attn_vec,
+                                        want_amean=want_aux)
     loss0, loss1 = dual_cross_entropy(sim)
     att_maps = split_attention_maps(attn, cap_lens, ih, iw)
-    return loss0, loss1, 0, 0, 0, att_maps
+    no_attn_loss = kl_loss = entropy_loss = 0
+    if want_aux:
+        shift = 0 if no_attn_vec is None else 1
+        no_attn_loss, kl_loss, entropy_loss = attention_regularisers(
+            amean, ih * iw + shift, shift, 0, no_attn_loss_weight, attention_divergence_loss_weight,
+            attention_entropy_loss_weight)
+    return loss0, loss1, no_attn_loss, kl_loss, entropy_loss, att_maps

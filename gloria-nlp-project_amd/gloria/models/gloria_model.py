@@ -108,20 +108,26 @@ class GLoRIA(nn.Module):
             attention_entropy_loss_weight=self.attention_entropy_loss_weight)
 
     def _calc_local_loss_sharded(self, img_emb_l, text_emb_l, cap_lens):
-        if (self.no_attn_loss_weight is not None or self.attention_divergence_loss_weight is not None
-                or self.attention_entropy_loss_weight is not None):
-            raise NotImplementedError("attention regularisers are not built yet (SURVEY.md 8f-1)")
+        want_aux = (self.no_attn_loss_weight is not None or self.attention_divergence_loss_weight is not None
+                    or self.attention_entropy_loss_weight is not None)
         d = self.dist
         b_loc = img_emb_l.shape[0]
         words_all = d.all_gather_grad(text_emb_l)                       # [B, D, L], grads reduce-scattered
         lens_all = d.all_gather_ints(cap_lens)
-        sim_rows, attn, _ = GL.local_similarity(img_emb_l, words_all, lens_all, self.temp1, self.temp2,
-                                                self.temp3, "sum", self.no_attn_vec, img_offset=d.rank * b_loc)
+        sim_rows, attn, amean = GL.local_similarity(img_emb_l, words_all, lens_all, self.temp1, self.temp2,
+                                                    self.temp3, "sum", self.no_attn_vec, img_offset=d.rank * b_loc,
+                                                    want_amean=want_aux)
         sim_full = d.all_gather_nograd(sim_rows)
         l0, l1 = GL.dual_cross_entropy(sim_rows, sim_full, d.rank * b_loc)
         ih, iw = img_emb_l.shape[2], img_emb_l.shape[3]
         maps = GL.split_attention_maps(attn, lens_all, ih, iw, first=d.rank * b_loc, count=b_loc)
-        return l0, l1, 0, 0, 0, maps
+        na = kl = ent = 0
+        if want_aux:       # this rank's share of the global-batch means (the shares of all ranks add up)
+            shift = 0 if self.no_attn_vec is None else 1
+            na, kl, ent = GL.attention_regularisers(amean, ih * iw + shift, shift, d.rank * b_loc,
+                                                    self.no_attn_loss_weight, self.attention_divergence_loss_weight,
+                                                    self.attention_entropy_loss_weight)
+        return l0, l1, na, kl, ent, maps
 
     def _calc_global_loss(self, img_emb_g, text_emb_g):
         if self.dist is not None and self.dist.active:

@@ -142,6 +142,10 @@ int glr_pack_words(const void* words_emb, int in_dtype, const int32_t* sent_slot
  *   pair_only    1: launch only the B_img diagonal (image b, tile of sentence img_offset+b) pairs;
  *                sim then only receives the diagonal entries (attention_fn, attention-finetune).
  *   img_offset   global index of local image 0 (data-parallel shard offset).
+ *   amean        optional out fp32 [B_img, n_sent, S_pad]: the word-mean attention row of EVERY pair,
+ *                A[b, i, r] = mean_w a2[b, i, w, r] (no-attention column at r = 0 when present, zeros for
+ *                r >= S_eff) - the input of the attention regularisers (gloria_loss.py:129-139; K6
+ *                glr_attn_reg_fwd).  NULL = not wanted.  bwd: damean = gradient w.r.t. amean (optional in).
  *
  * bwd outputs, consumed by three plain GEMMs on the caller's BLAS:
  *   xout  [n_slots, B_img, S_pad] op dtype   X = ds + alpha*a2 :
@@ -157,15 +161,15 @@ int glr_local_attn_fwd(const void* vt, const void* gram, const void* tp, const f
                        const int32_t* pair_tile, int n_pair, int n_tiles, int n_sent, int B_img, int D, int S_eff,
                        float temp1, float temp2, float temp3, int agg, float eps, float* sim, int ld_sim,
                        float* lse, float* wstat, float* attn, const int64_t* attn_off, int strip, int pair_only,
-                       int img_offset, int op_dtype, void* stream);
+                       int img_offset, float* amean, int op_dtype, void* stream);
 
 int glr_local_attn_bwd(const void* vt, const void* gram, const void* tp, const float* tnorm,
                        const int32_t* sent_slot0, const int32_t* cap_lens, const int32_t* tile_first,
                        const int32_t* order, const int32_t* tile_nsub, const int32_t* item_tile, int n_items,
                        int n_tiles, int n_sent, int B_img, int D, int S_eff, float temp1, float temp2, float temp3,
                        int agg, float eps, const float* sim, const float* dsim, int ld_sim, const float* lse,
-                       const float* wstat, void* xout, void* aout, float* gamma, float* beta, int op_dtype,
-                       void* stream);
+                       const float* wstat, const float* damean, void* xout, void* aout, float* gamma, float* beta,
+                       int op_dtype, void* stream);
 
 /* K-tiling of the K1 operands (device, HBM-bound copy).  glr_local_attn_fwd / _bwd take vt, gram and tp in
  * the K-TILED layout: every block of `rows` rows (vt, gram: the S_pad rows of one image; tp: the 64 slots of one
@@ -238,6 +242,22 @@ int glr_cosine_fwd(const float* x1, const float* x2, int rows, int D, float eps,
                    void* stream);
 int glr_cosine_bwd(const float* x1, const float* x2, const float* stats, const float* g, int rows, int D, float eps,
                    float* dx1, float* dx2, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K6  attention regularisers of local_loss (gloria_loss.py:108-114, 129-139, 172-199) on the word-mean
+ * attention rows of ALL pairs (amean of glr_local_attn_fwd).  With shift = 1 (no-attention column present)
+ * the rows are P = [1 - sum_{r>=1} A[r], A[1:]] (:133-135), else P = A.
+ *   out[b, 0] = sum_i entropy(P[b, i])                               entropy (:95-96)
+ *   out[b, 1] = sum_{i != d} 1/2 [KL(P[b,d] || P[b,i]) + KL(P[b,i] || P[b,d])],  d = img_offset + b   (:180-190)
+ *   out[b, 2] = log(1 - sum_{r >= shift} A[b, d, r])                 no-attention score of the diagonal pair (:130)
+ * The caller forms the reference's means / weights.  bwd: damean = gradient of
+ * coef[0] * sum_b out[b,0] + coef[1] * sum_b out[b,1] + coef[2] * sum_b out[b,2]  (coef: 3 device floats).
+ * HBM-bound (B_img * n_sent * S_pad * 4 bytes read); fixed summation order (bitwise reproducible).
+ */
+int glr_attn_reg_fwd(const float* amean, int B_img, int n_sent, int S_pad, int S_eff, int shift, int img_offset,
+                     float* out, void* stream);
+int glr_attn_reg_bwd(const float* amean, int B_img, int n_sent, int S_pad, int S_eff, int shift, int img_offset,
+                     const float* coef, float* damean, void* stream);
 
 #ifdef __cplusplus
 }

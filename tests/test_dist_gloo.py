@@ -42,19 +42,38 @@ def _patch_with_oracle():
     from oracle import gloria_oracle as orc
 
     def local_similarity(img, words, cap_lens, temp1=4.0, temp2=5.0, temp3=10.0, agg="sum", no_attn_vec=None,
-                         eps=1e-8, want_attn=True, img_offset=0, word_start=0):
+                         eps=1e-8, want_attn=True, img_offset=0, word_start=0, want_amean=False):
         sim, a2, seg = orc.local_similarity_matrix(img, words, cap_lens, temp1, temp2, temp3, agg, no_attn_vec,
                                                    return_attn=True)
         woff = np.concatenate([[0], np.cumsum(cap_lens)])
         S = img.shape[2] * img.shape[3]
+        shift = a2.shape[-1] - S                     # 1 with a no-attention column
         flat = torch.zeros(int(woff[-1]) * S)
         parts = []
         for b in range(img.shape[0]):
             i = img_offset + b
-            parts.append((int(woff[i]) * S, a2[b, woff[i]:woff[i + 1]].reshape(-1)))
+            parts.append((int(woff[i]) * S, a2[b, woff[i]:woff[i + 1], shift:].reshape(-1)))
         for off, p in parts:
             flat = torch.cat([flat[:off], p, flat[off + p.numel():]])
-        return sim, flat, None
+        amean = None
+        if want_amean:        # word-mean attention rows of all pairs, padded like the kernel's output
+            rows = torch.stack([a2[:, woff[i]:woff[i + 1]].mean(1) for i in range(len(cap_lens))], 1)
+            amean = torch.nn.functional.pad(rows, (0, 64 - rows.shape[-1] % 64))
+        return sim, flat, amean
+
+    def attention_regularisers(amean, s_eff, shift, img_offset, w_na, w_kl, w_ent):
+        """torch restatement of K6 + the reference's means (this rank's share of the global-batch means)."""
+        A = amean[:, :, :s_eff]
+        n = amean.shape[1]
+        P = torch.cat([1 - A[:, :, 1:].sum(-1, keepdim=True), A[:, :, 1:]], -1) if shift else A
+        idx = torch.arange(A.shape[0])
+        Pd = P[idx, img_offset + idx].unsqueeze(1)
+        ent = -(P * P.log()).sum(-1)
+        kl = 0.5 * ((Pd - P) * (Pd.log() - P.log())).sum(-1)
+        na = torch.log(1 - A[idx, img_offset + idx][:, shift:].sum(-1))
+        return ((w_na * na.sum() / n) if w_na is not None else 0,
+                (w_kl * -(kl.sum() / (n * (n - 1)))) if w_kl is not None else 0,
+                (ent.sum() / (n * n)) if w_ent is not None else 0)
 
     def dual_cross_entropy(sim_rows, sim_full=None, row0=0):
         if sim_full is None:
@@ -63,11 +82,12 @@ def _patch_with_oracle():
         return orc.dual_ce(full)
 
     GL.local_similarity = local_similarity
+    GL.attention_regularisers = attention_regularisers
     GL.dual_cross_entropy = dual_cross_entropy
     GL.global_similarity = lambda a, t, eps=1e-8, temp3=10.0: orc.global_similarity_matrix(a, t, eps, temp3)
 
 
-def _bare_gloria(dctx):
+def _bare_gloria(dctx, aux=False):
     from gloria.models.gloria_model import GLoRIA
     g = GLoRIA.__new__(GLoRIA)
     torch.nn.Module.__init__(g)
@@ -77,6 +97,9 @@ def _bare_gloria(dctx):
     g.local_loss_weight = g.global_loss_weight = 1.0
     g.no_attn_loss_weight = g.attention_divergence_loss_weight = g.attention_entropy_loss_weight = None
     g.segmentation_loss_weight = None
+    if aux:          # the flags of the reference's training command (submit_job.sh:15)
+        g.no_attn_vec = torch.nn.Parameter(torch.from_numpy(gi.normal(15, D)))
+        g.no_attn_loss_weight, g.attention_divergence_loss_weight, g.attention_entropy_loss_weight = 1.0, 0.1, 1.0
     return g
 
 
@@ -116,7 +139,14 @@ def _worker(rank, port, out):
         lin(x).sum().backward()
         red.finish()
         rgrads = [p.grad.clone() for p in plist]
-        torch.save({"loss": loss.detach(), "gi": li.grad, "gw": lw.grad, "gig": lig.grad, "gtg": ltg.grad,
+        # same step with the no-attention vector and the three attention regularisers switched on
+        ga = _bare_gloria(dctx, aux=True)
+        ai, aw = img[sl].clone().requires_grad_(True), words[sl].clone().requires_grad_(True)
+        l0, l1, na, kl, ent, _ = ga._calc_local_loss(ai, aw, Sents())
+        (l0 + l1 + na + kl + ent).backward()      # l0 / l1: full value, gradient of this rank's rows only; aux terms: shares
+        aux = {"l": [float(l0), float(l1)], "shares": [float(na), float(kl), float(ent)], "gi": ai.grad, "gw": aw.grad,
+               "gna": ga.no_attn_vec.grad}
+        torch.save({"loss": loss.detach(), "gi": li.grad, "gw": lw.grad, "gig": lig.grad, "gtg": ltg.grad, "aux": aux,
                     "maps": [m.detach() for m in maps], "p0": p[0].grad, "p1": p[1].grad, "ints": ints, "rgrads": rgrads},
                    os.path.join(out, f"r{rank}.pt"))
     finally:
@@ -149,6 +179,21 @@ def test_sharded_loss_equals_full_batch(tmp_path):
             np.testing.assert_allclose(res[r]["maps"][k].numpy(), l[5][r * per + k].detach().numpy(), rtol=1e-5, atol=1e-7)
         assert torch.equal(res[r]["p0"], torch.full((5,), 3.0)) and torch.equal(res[r]["p1"], torch.full((3, 2), 30.0))
         assert res[r]["ints"] == [0, 10, 1, 11]
+    # attention regularisers: the rank shares add up to the single-process values; gradients likewise
+    ai, aw = img.clone().requires_grad_(True), words.clone().requires_grad_(True)
+    nav = torch.from_numpy(gi.normal(15, D)).requires_grad_(True)
+    ref = orc.local_loss(ai, aw, CAP, no_attn_vec=nav, no_attn_loss_weight=1.0, attention_divergence_loss_weight=0.1,
+                         attention_entropy_loss_weight=1.0)
+    (ref[0] + ref[1] + ref[2] + ref[3] + ref[4]).backward()
+    shares = np.sum([res[r]["aux"]["shares"] for r in range(WORLD)], 0)
+    np.testing.assert_allclose(shares, [float(ref[2]), float(ref[3]), float(ref[4])], rtol=1e-5, atol=1e-6)
+    gna = sum(res[r]["aux"]["gna"] for r in range(WORLD))
+    np.testing.assert_allclose(gna.numpy(), nav.grad.numpy(), rtol=1e-4, atol=2e-6)
+    for r in range(WORLD):
+        sl = slice(r * per, (r + 1) * per)
+        np.testing.assert_allclose(res[r]["aux"]["l"], [float(ref[0]), float(ref[1])], rtol=1e-5)
+        np.testing.assert_allclose(res[r]["aux"]["gi"].numpy(), ai.grad[sl].numpy(), rtol=1e-4, atol=2e-6)
+        np.testing.assert_allclose(res[r]["aux"]["gw"].numpy(), aw.grad[sl].numpy(), rtol=1e-4, atol=2e-6)
     # reducer: every rank ends with the SUM over ranks of the single-process gradients
     torch.manual_seed(0)
     lin = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Tanh(), torch.nn.Linear(5, 3), torch.nn.Linear(3, 1))

@@ -71,6 +71,64 @@ def test_local_loss_golden(golden, name):
         check(gd, f"local/{name}/grad_no_attn", tna.grad, rtol=2e-3, atol=2e-6)
 
 
+@pytest.mark.parametrize("name", [n for n, c in gi.LOCAL_CASES.items() if c["aux"] is not None])
+def test_local_loss_with_attention_regularisers_golden(golden, name):
+    """The reference's training flags (--no_attn_vec + no-attention / divergence / entropy regularisers,
+    gloria_loss.py:108-114, 129-139, 172-199): all five losses and the gradients of their sum against the
+    outputs of the real reference, fp32 mode."""
+    gd = golden("local")
+    cfg = gi.LOCAL_CASES[name]
+    img, words, cap_lens, na = gi.local_inputs(name)
+    timg, twords, tna = g(img, True), g(words, True), g(na, True)
+    aux = cfg["aux"]
+    l0, l1, nal, kl, ent, maps = gl().local_loss(timg, twords, cap_lens, agg=cfg["agg"], no_attn_vec=tna,
+                                                 no_attn_loss_weight=aux[0], attention_divergence_loss_weight=aux[1],
+                                                 attention_entropy_loss_weight=aux[2])
+    got = [float(x.detach()) for x in (l0, l1, nal, kl, ent)]
+    np.testing.assert_allclose(got, gd[f"local/{name}/losses"], rtol=1e-4, atol=1e-4)
+    check(gd, f"local/{name}/maps", torch.cat([m.reshape(-1) for m in maps]), rtol=1e-4, atol=1e-6)
+    (l0 + l1 + nal + kl + ent).backward()
+    check(gd, f"local/{name}/grad_img", timg.grad, rtol=2e-3, atol=2e-6)
+    check(gd, f"local/{name}/grad_words", twords.grad, rtol=2e-3, atol=2e-6)
+    check(gd, f"local/{name}/grad_no_attn", tna.grad, rtol=2e-3, atol=2e-6)
+
+
+@pytest.mark.parametrize("no_attn", [True, False])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_attention_regularisers_vs_oracle(dtype, no_attn):
+    """Regularisers through the production kernels (bf16: pair kernel + single-tile backward; fp32: 32-word
+    tiles) at 361/362 regions with ragged sentences, against the oracle on the same (rounded) inputs."""
+    B, D, H, W, L = 12, 768, 19, 19, 97
+    cap_lens = [70, 40, 33, 23, 22, 17, 11, 9, 5, 5, 2, 1]
+    seed = 4242
+    img, words = g(gi.normal(seed, B, D, H, W)).to(dtype), g(gi.normal(seed + 1, B, D, L)).to(dtype)
+    na = g(gi.normal(seed + 2, D, std=1.0)).to(dtype) if no_attn else None
+    w = (1.0, 0.1, 1.0) if no_attn else (None, 0.1, 1.0)      # the no-attention score needs the extra column
+    ti, tw = img.clone().requires_grad_(True), words.clone().requires_grad_(True)
+    tn = None if na is None else na.clone().requires_grad_(True)
+    out = gl().local_loss(ti, tw, cap_lens, no_attn_vec=tn, no_attn_loss_weight=w[0],
+                          attention_divergence_loss_weight=w[1], attention_entropy_loss_weight=w[2])
+    sum(x for x in out[:5] if torch.is_tensor(x)).backward()
+    ri, rw = img.float().cpu().requires_grad_(True), words.float().cpu().requires_grad_(True)
+    rn = None if na is None else na.float().cpu().requires_grad_(True)
+    ref = orc().local_loss(ri, rw, cap_lens, no_attn_vec=rn, no_attn_loss_weight=w[0],
+                           attention_divergence_loss_weight=w[1], attention_entropy_loss_weight=w[2])
+    sum(x for x in ref[:5] if torch.is_tensor(x)).backward()
+    f32 = dtype == torch.float32
+    for k in (2, 3, 4):                                       # no-attention, divergence, entropy
+        if torch.is_tensor(ref[k]):
+            np.testing.assert_allclose(float(out[k].detach()), float(ref[k]), rtol=1e-4 if f32 else 2e-2,
+                                       atol=1e-5 if f32 else 2e-3)
+    rt, at = (2e-3, 1e-5) if f32 else (0.1, 2e-3)        # fp32: sums over 12 x 237 words x 362 regions, 1e-5 absolute noise floor
+    pairs = [(ti.grad, ri.grad), (tw.grad, rw.grad)] + ([] if tn is None else [(tn.grad, rn.grad)])
+    for a, b in pairs:
+        a, b = a.float().cpu().numpy(), b.numpy()
+        if f32:
+            np.testing.assert_allclose(a, b, rtol=rt, atol=at)
+        else:                                                 # bf16 operands: relative error of the whole tensor
+            assert np.linalg.norm(a - b) / np.linalg.norm(b) < 0.05
+
+
 @pytest.mark.parametrize("name", list(gi.SIM_CASES))
 def test_sim_matrix_golden(golden, name):
     gd = golden("sim")

@@ -100,9 +100,12 @@ def test_synthetic_batch_contract():
     assert (frac > 0.03).all() and (frac < 0.5).all()
 
 
-def test_loss_refuses_cpu_and_unbuilt_features():
+def test_loss_refuses_cpu_tensors():
+    """No CPU / eager fallback: the product path raises on CPU tensors (with or without the regularisers)."""
     from gloria.loss import gloria_loss as GL
     with pytest.raises(RuntimeError):
         GL.global_loss(torch.zeros(2, 64), torch.zeros(2, 64))
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(RuntimeError):
+        GL.local_loss(torch.zeros(2, 64, 3, 3), torch.zeros(2, 64, 5), [2, 2])
+    with pytest.raises(RuntimeError):
         GL.local_loss(torch.zeros(2, 64, 3, 3), torch.zeros(2, 64, 5), [2, 2], no_attn_loss_weight=1.0)
