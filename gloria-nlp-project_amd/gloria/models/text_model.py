@@ -159,6 +159,16 @@ class WordpieceSegSumFn(torch.autograd.Function):
         return (None, None) + tuple(dh.to(dt) for dt in dts)
 
 
+def host_ids(ids):
+    """caption ids as a host array WITHOUT a device sync when the trainer kept the host copy (Trainer.to_device
+    attaches it as `_glr_host`); a plain `.cpu()` here would drain the stream every step (the image encoder is
+    already queued) and expose the launch latency of everything behind it."""
+    host = getattr(ids, "_glr_host", None)
+    if host is not None:
+        return host
+    return ids.detach().cpu().numpy() if torch.is_tensor(ids) else np.asarray(ids)
+
+
 class BertEncoder(nn.Module):
     def __init__(self, cfg):
         super().__init__()
@@ -196,7 +206,7 @@ class BertEncoder(nn.Module):
 
     def aggregate_tokens(self, embeddings, caption_ids):
         """embeddings [B, L, D] (already reduced over layers) -> word slots [B, L, D], sents."""
-        ids = caption_ids.detach().cpu().numpy() if torch.is_tensor(caption_ids) else np.asarray(caption_ids)
+        ids = host_ids(caption_ids)
         B, L = ids.shape
         dst, starts, n_words = wordpiece_slots(ids, self.vocab)
         sents = SentenceBatch(ids, dst, starts, n_words, self.vocab, L)
@@ -217,7 +227,7 @@ class BertEncoder(nn.Module):
                 raise Exception("Aggregation method not implemented")
             if self.agg_tokens and layers[0].is_cuda and self.last_n_layers <= 4 and layers[0].shape[2] % 64 == 0:
                 # K5: segment-sum fused with the layer reduction and the L-mean, [B, D, L] written directly
-                host = ids.detach().cpu().numpy()
+                host = host_ids(ids)
                 B, L = host.shape
                 dst, starts, n_words = wordpiece_slots(host, self.vocab)
                 sents = SentenceBatch(host, dst, starts, n_words, self.vocab, L)
@@ -231,12 +241,12 @@ class BertEncoder(nn.Module):
                     word_embeddings, sents = self.aggregate_tokens(embeddings, ids)
                 else:
                     word_embeddings = embeddings
-                    host = ids.detach().cpu().numpy()
+                    host = host_ids(ids)
                     sents = [[self.vocab.tokens[int(w)] for w in sent] for sent in host]
                 sent_embeddings = word_embeddings.mean(dim=1)          # over ALL L slots (ref :110)
         else:
             word_embeddings, sent_embeddings = outputs[0], outputs[1]
-            host = ids.detach().cpu().numpy()
+            host = host_ids(ids)
             sents = [[self.vocab.tokens[int(w)] for w in sent] for sent in host]
 
         batch_dim, num_words, feat_dim = word_embeddings.shape

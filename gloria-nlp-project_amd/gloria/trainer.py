@@ -48,9 +48,12 @@ class Trainer:
         out = {}
         for k, v in batch.items():
             if torch.is_tensor(v):
+                host = v.numpy() if (k == "caption_ids" and v.device.type == "cpu") else getattr(v, "_glr_host", None)
                 v = v.to(self.device, non_blocking=True)
                 if k == "imgs" and self.device.type == "cuda":
                     v = v.contiguous(memory_format=torch.channels_last)
+                if host is not None:
+                    v._glr_host = host           # the word-piece slotting runs on the host: no D2H sync per step
             out[k] = v
         return out
 
