@@ -37,7 +37,13 @@
 //
 // Wave w: wm = w & 1 -> 32-word block; wg = w >> 1 -> region blocks {wg, wg+4, wg+8}.
 // Accumulator element q of a block: word row (q&3) + 8*(q>>2) + 4*(lane>>5), region column lane&31.
+#include <cstdlib>
+
 #include "glr_common.h"
+
+#ifndef GLR_STAGGER
+#define GLR_STAGGER 1
+#endif
 
 extern "C" int glr_region_pad(int s_eff) { return (s_eff + 63) / 64 * 64; }
 // populated word slots per 64-slot tile: the fp32 mode keeps a 32-word score tile + fp32 image in LDS
@@ -76,6 +82,7 @@ struct LaParams {
   const long long* attn_off;
   int strip;
   int pair_only, img_offset;
+  int img_block;                // pair kernel: images per L2 group (block -> (image, item) mapping)
   // backward only
   const float* dsim;            // [B_img][ld_sim]
   unsigned char* xout;          // [n_slots][B_img][S_pad] op dtype
@@ -160,6 +167,7 @@ __device__ __forceinline__ void stream_gemm_n(f32x16 (&acc)[3], f32x16 (&acc2)[3
                                               int wg, int nrb, int tw) {
   constexpr int PPR = CHB / 16, RPB = 256 / CHB, KSTEPS = CHB / 32, RPI = 64 / PPR;
   constexpr int PDD = NB - 1;                          // chunks issued ahead; buffer (c+PDD) % NB == (c-1) % NB
+  constexpr bool STAG = GLR_STAGGER && PDD == 3;
   static_assert(PDD == 1 || PDD == 3, "wait immediates are written for 2- and 4-deep rings");
   // the per-lane address tables below are loop invariant w.r.t. the caller's tile loops; laundering the
   // lane id keeps hipcc from hoisting all of them (x8 template instances) to kernel entry, where they
@@ -235,13 +243,18 @@ __device__ __forceinline__ void stream_gemm_n(f32x16 (&acc)[3], f32x16 (&acc2)[3
     }
   };
 
+  // Waves w and w + 4 share a SIMD and leave every barrier together.  If both first issue their DMA pieces
+  // (~100 cycles of issue each) the matrix pipe idles meanwhile and is contended afterwards, so (4-deep ring
+  // only) waves 4-7 issue AFTER their MFMAs: one partner's DMA issue overlaps the other's matrix work.
+  const bool late = STAG && wave >= 4;
   for (int c = 0; c < PDD && c < nchunk; ++c) issue(c);
   int c = 0;
   for (; c + PDD <= nchunk; ++c) {                       // steady state: PDD-1 younger chunks stay in flight
     wait_vm<(PDD - 1) * NPWC>();
     wg_barrier();
-    if (c + PDD < nchunk) issue(c + PDD);
+    if (!late && c + PDD < nchunk) issue(c + PDD);
     compute(c);
+    if (late && c + PDD < nchunk) issue(c + PDD);
   }
   for (; c < nchunk; ++c) {                              // tail (PDD == 3 only): nchunk-1-c younger chunks in flight
     if (nchunk - 1 - c == 1) wait_vm<NPWC>(); else wait_vm<0>();
@@ -819,11 +832,17 @@ __global__ void __launch_bounds__(NTHR) k_local_attn_pair(LaParams p) {
   const int wm = wave & 1, wg = wave >> 1;
   const int l31 = lane & 31, h = lane >> 5;
 
+  // Block -> (image, item).  Blocks with equal blockIdx % 8 share an XCD (speed only).  Per XCD the blocks walk
+  // groups of `img_block` images x all items, images innermost: the XCD's concurrently resident workgroups then
+  // share img_block images (vt + gram: 885 KB each) AND a few word-tile pairs (196 KB each) in the 4 MiB L2,
+  // instead of re-fetching all 9 MB of packed words from the Infinity Cache for every single image.
   const int xcd = blockIdx.x & 7, qq = blockIdx.x >> 3;
-  const int b = (qq / p.n_items) * 8 + xcd;
+  const int ib = p.img_block;
+  const int grp = qq / (ib * p.n_items), rem = qq - grp * (ib * p.n_items);
+  const int b = (grp * ib + rem % ib) * 8 + xcd;
   if (b >= p.B_img) return;
   GLR_STAMP2(0);
-  const int tile0 = p.item_tile[qq % p.n_items];
+  const int tile0 = p.item_tile[rem / ib];
   const int D = p.D;
 
   unsigned char* ring = smem;
@@ -1177,7 +1196,11 @@ int launch_pair(LaParams& p, int op_dtype, void* stream) {
   if (p.S_pad != GLR_MAX_SPAD) return GLR_EINVAL;   // the pair kernel is built for the 384-region shape only
   const int lds = carve_pair(p, op_dtype, p.S_pad);
   if (lds > 160 * 1024) return GLR_EINVAL;
-  const int grid = ((p.B_img + 7) / 8) * 8 * p.n_items;
+  // images per XCD rounded up to a multiple of the L2 group size
+  static const int env_ib = [] { const char* e = getenv("GLR_K1_IMG_BLOCK"); return e ? atoi(e) : 0; }();
+  p.img_block = env_ib > 0 ? env_ib : 4;
+  const int per_xcd = ((p.B_img + 7) / 8 + p.img_block - 1) / p.img_block * p.img_block;
+  const int grid = per_xcd * 8 * p.n_items;
   if (hipFuncSetAttribute((const void*)k_local_attn_pair<OpBF16>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return GLR_ELAUNCH;
   hipLaunchKernelGGL((k_local_attn_pair<OpBF16>), dim3(grid), dim3(NTHR), lds, (hipStream_t)stream, p);
   GLR_CHECK_LAUNCH();
