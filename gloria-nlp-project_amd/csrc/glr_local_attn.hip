@@ -79,6 +79,7 @@ struct LaParams {
   float* attn;                  // fwd optional out
   float* amean;                 // fwd optional out: [B_img][n_sent][S_pad] word-mean attention row of every pair
   const float* damean;          // bwd optional in:  gradient w.r.t. amean
+  const float* dattn;           // bwd optional in:  gradient w.r.t. the diagonal attention maps (layout of attn)
   const long long* attn_off;
   int strip;
   int pair_only, img_offset;
@@ -514,10 +515,16 @@ __global__ void __launch_bounds__(NTHR) k_local_attn(LaParams p) {
       int cur = -2;
       float lcur[3] = {0.f, 0.f, 0.f};
       float gcur[3] = {0.f, 0.f, 0.f};     // bwd: gradient of the word-mean attention row / words in the sentence
+      // bwd: gradient of the attention map of the diagonal pair (attention-supervision loss), per (word, region)
+      const bool has_dmap = BWD && p.dattn != nullptr;
+      const int dw0 = has_dmap ? diag[0] : 0, dn = has_dmap ? diag[1] : 0;
+      const int sout = p.S_eff - p.strip;
+      const float* dmap = has_dmap ? p.dattn + p.attn_off[p.img_offset + b] + (size_t)wbase * sout - p.strip : nullptr;
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         const int word = wm * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
         const int sg = wseg[word];
+        const bool in_diag = has_dmap && word >= dw0 && word < dw0 + dn;
         float zi = 0.f, be = 0.f, al = 0.f;
         if (BWD) { zi = w_zi[word]; be = w_be[word]; al = w_al[word]; }
         if (sg != cur && sg >= 0) {
@@ -548,10 +555,12 @@ __global__ void __launch_bounds__(NTHR) k_local_attn(LaParams p) {
             if (BWD) {
               // da2 = (alpha s - beta u) + g: the accumulator starts at -(alpha s + g), P3 adds beta u
               const float a2 = e2 * zi;
+              float ge = gcur[j];
+              if (in_diag && ok && region >= p.strip) ge += dmap[(size_t)(word - dw0) * sout + region];
               O::from_f32(img + word * IMP + region * ESZ, be * a2);
               a1r[j][q] = a1;
-              acc[j][q] = -al * acc[j][q] - (ok ? gcur[j] : 0.f);
-              zacc += a2 * gcur[j];              // kappa gains sum_r a2 g  (softmax-over-regions backward)
+              acc[j][q] = -al * acc[j][q] - (ok ? ge : 0.f);
+              zacc += a2 * ge;                   // kappa gains sum_r a2 g  (softmax-over-regions backward)
             } else {
               O::from_f32(img + word * IMP + region * ESZ, e2);
               const float e2r = ESZ == 4 ? e2 : bf2f(f2bf(e2));        // as the MFMA will see it
@@ -577,7 +586,7 @@ __global__ void __launch_bounds__(NTHR) k_local_attn(LaParams p) {
           red[(1 * 8 + rslot) * TW + word] = d;
         }
       }
-    } else if (p.damean != nullptr) {
+    } else if (p.damean != nullptr || p.dattn != nullptr) {
       const int rslot = wg * 2 + ((lane >> 4) & 1);
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
@@ -589,7 +598,7 @@ __global__ void __launch_bounds__(NTHR) k_local_attn(LaParams p) {
       }
     }
     __syncthreads();        // image complete (and the score tile is dead: the ring may be reused)
-    if (BWD && p.damean != nullptr && tid < TW) {
+    if (BWD && (p.damean != nullptr || p.dattn != nullptr) && tid < TW) {
       float kg = 0.f;
 #pragma unroll
       for (int k = 0; k < 8; ++k) kg += red[(8 + k) * TW + tid];
@@ -1219,7 +1228,7 @@ int fill_common(LaParams& p, const void* vt, const void* gram, const void* tp, c
   if (agg < 0 || agg > 2) return GLR_EINVAL;
   p.vt = (const unsigned char*)vt; p.gram = (const unsigned char*)gram; p.tp = (const unsigned char*)tp;
   p.tnorm = tnorm; p.sent_slot0 = sent_slot0; p.cap_lens = cap_lens; p.tile_first = tile_first; p.order = order;
-  p.tile_nsub = tile_nsub; p.item_tile = nullptr; p.n_items = 0; p.amean = nullptr; p.damean = nullptr; p.n_tiles = n_tiles; p.n_sent = n_sent;
+  p.tile_nsub = tile_nsub; p.item_tile = nullptr; p.n_items = 0; p.amean = nullptr; p.damean = nullptr; p.dattn = nullptr; p.n_tiles = n_tiles; p.n_sent = n_sent;
   p.n_slots = n_tiles * TW; p.B_img = B_img;
   p.D = D; p.S_eff = S_eff; p.S_pad = S_pad; p.temp1 = temp1; p.temp2 = temp2; p.temp3 = temp3; p.agg = agg;
   p.eps = eps;
@@ -1273,8 +1282,9 @@ extern "C" int glr_local_attn_bwd(const void* vt, const void* gram, const void* 
                                   const int32_t* item_tile, int n_items, int n_tiles, int n_sent, int B_img, int D,
                                   int S_eff, float temp1, float temp2, float temp3, int agg, float eps,
                                   const float* sim, const float* dsim, int ld_sim, const float* lse,
-                                  const float* wstat, const float* damean, void* xout, void* aout, float* gamma,
-                                  float* beta, int op_dtype, void* stream) {
+                                  const float* wstat, const float* damean, const float* dattn,
+                                  const int64_t* attn_off, int strip, int img_offset, void* xout, void* aout,
+                                  float* gamma, float* beta, int op_dtype, void* stream) {
   LaParams p;
   const int rc = fill_common(p, vt, gram, tp, tnorm, sent_slot0, cap_lens, tile_first, order, tile_nsub, n_tiles,
                              n_sent, B_img, D, S_eff, temp1, temp2, temp3, agg, eps, op_dtype);
@@ -1283,7 +1293,10 @@ extern "C" int glr_local_attn_bwd(const void* vt, const void* gram, const void* 
   if (agg == GLR_AGG_MAX) return GLR_EINVAL;      // max aggregation is inference-only (gloria_model.py:199)
   p.sim = const_cast<float*>(sim); p.dsim = dsim; p.ld_sim = ld_sim; p.lse = const_cast<float*>(lse);
   p.wstat = const_cast<float*>(wstat); p.xout = (unsigned char*)xout; p.aout = (unsigned char*)aout;
+  if (dattn && !attn_off) return GLR_EINVAL;
+  if (img_offset < 0 || img_offset + B_img > n_sent) return GLR_EINVAL;
   p.gamma = gamma; p.beta = beta; p.item_tile = item_tile; p.n_items = n_items; p.damean = damean;
+  p.dattn = dattn; p.attn_off = (const long long*)attn_off; p.strip = strip; p.img_offset = img_offset;
   return launch<true>(p, op_dtype, stream);
 }
 

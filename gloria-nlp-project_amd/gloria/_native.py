@@ -35,8 +35,13 @@ SYMBOLS = {
                                    c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
                                    # ..., sim, ld, lse, wstat, attn, attn_off, strip, pair_only, img_offset, amean, dtype, stream
     "glr_local_attn_bwd": (c_int, [c_void_p] * 10 + [c_int] * 6 + [c_float] * 3 + [c_int, c_float, c_void_p, c_void_p,
-                                   c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
-                                   c_void_p]),      # sim, dsim, ld, lse, wstat, damean, xout, aout, gamma, beta, dtype, stream
+                                   c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                   c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+                                   # sim, dsim, ld, lse, wstat, damean, dattn, attn_off, strip, img_offset,
+                                   # xout, aout, gamma, beta, dtype, stream
+    "glr_kth_value": (c_int, [c_void_p, c_int, ctypes.c_longlong, ctypes.c_longlong, c_void_p, c_void_p]),
+    "glr_topk_desc": (c_int, [c_void_p, c_int, ctypes.c_longlong, c_int, c_void_p, c_void_p, c_void_p]),
+    "glr_threshold_counts": (c_int, [c_void_p, c_void_p, c_void_p, c_int, ctypes.c_longlong, c_void_p, c_void_p]),
     "glr_attn_reg_fwd": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "glr_attn_reg_bwd": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "glr_dual_ce_fwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -119,10 +119,11 @@ def _k1_args(plan, vt, gram, tp, tnorm, B, D, s_eff, o, backward=False):
 
 
 class LocalSimFn(torch.autograd.Function):
-    """sim[b, i] for local images x all sentences (+ diagonal attention maps).  HIP forward (K1) and
-    HIP backward (K1 bwd + three plain GEMMs); the gradient THROUGH THE ATTENTION MAPS themselves
-    (attention-supervision loss, attention_fn outputs) still uses the torch restatement of the B
-    diagonal pairs in loss/_recompute.py."""
+    """sim[b, i] for local images x all sentences (+ diagonal attention maps, + word-mean attention rows).
+    HIP forward (K1) and HIP backward (K1 bwd + three plain GEMMs), including the gradients that arrive
+    through the diagonal attention maps (attention-supervision loss) and through the word-mean rows
+    (regularisers).  Only the standalone attention_fn outputs (pair mode: maps + weighted context of B
+    pairs) are differentiated through the torch restatement in loss/_recompute.py."""
 
     @staticmethod
     def forward(ctx, img_features, words_emb, no_attn_vec, cap_lens, opts):
@@ -188,12 +189,20 @@ class LocalSimFn(torch.autograd.Function):
         d_na = None if no_attn_vec is None else torch.zeros(D, dtype=torch.float32, device=dev)
 
         have_dam = o.want_amean and damean is not None and damean.numel() > 0
-        if (dsim is not None or have_dam) and not o.pair_only:
+        need_attn = o.want_attn and dattn is not None and dattn.numel() > 0
+        need_wctx = o.want_wctx and dwctx is not None and dwctx.numel() > 0
+        # the gradient of the diagonal attention maps (attention-supervision loss) goes through K1 backward too;
+        # only attention_fn's own outputs (pair mode / weighted context) keep the torch restatement below
+        hip_attn = need_attn and not o.pair_only and not o.want_wctx
+        if (dsim is not None or have_dam or hip_attn) and not o.pair_only:
             if lse is None:
                 raise RuntimeError("local similarity was computed without gradient state")
             if dsim is None:
                 dsim = torch.zeros_like(sim)
             dam = damean.float().contiguous() if have_dam else None
+            dat = dattn.float().contiguous() if hip_attn else None
+            strip = 0 if o.want_wctx else shift
+            dat_off = plan.attn_offsets(s_eff - strip, dev)[0] if hip_attn else None
             odt = vt.dtype
             ns = plan.n_slots
             xout = torch.empty(ns, B, s_pad, dtype=odt, device=dev)
@@ -202,7 +211,8 @@ class LocalSimFn(torch.autograd.Function):
             beta = torch.empty(B, ns, dtype=torch.float32, device=dev)
             g = dsim.float().contiguous()
             N.check(L.glr_local_attn_bwd(*_k1_args(plan, vt_t, gram_t, tp_t, tnorm, B, D, s_eff, o, True), N.ptr(sim), N.ptr(g),
-                                         plan.n_sent, N.ptr(lse), N.ptr(wstat), N.ptr(dam), N.ptr(xout), N.ptr(aout),
+                                         plan.n_sent, N.ptr(lse), N.ptr(wstat), N.ptr(dam), N.ptr(dat), N.ptr(dat_off),
+                                         strip, o.img_offset, N.ptr(xout), N.ptr(aout),
                                          N.ptr(gamma), N.ptr(beta), code, N.stream()), "glr_local_attn_bwd")
             # gradient GEMMs (plain library GEMMs on the kernel's outputs)
             x2d = xout.view(ns, B * s_pad)
@@ -215,8 +225,7 @@ class LocalSimFn(torch.autograd.Function):
             if d_na is not None:
                 d_na += dvt[:, 0].sum(0)
 
-        need_attn = o.want_attn and dattn is not None and dattn.numel() > 0
-        need_wctx = o.want_wctx and dwctx is not None and dwctx.numel() > 0
+        need_attn = need_attn and not hip_attn
         if need_attn or need_wctx:
             # gradient through the attention maps of the B diagonal pairs (torch restatement, small)
             img = img_features.detach().float().reshape(B, D, -1)

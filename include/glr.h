@@ -146,6 +146,8 @@ int glr_pack_words(const void* words_emb, int in_dtype, const int32_t* sent_slot
  *                A[b, i, r] = mean_w a2[b, i, w, r] (no-attention column at r = 0 when present, zeros for
  *                r >= S_eff) - the input of the attention regularisers (gloria_loss.py:129-139; K6
  *                glr_attn_reg_fwd).  NULL = not wanted.  bwd: damean = gradient w.r.t. amean (optional in).
+ *   dattn        bwd optional in: gradient w.r.t. the diagonal attention maps, same packed layout as attn
+ *                (attn_off / strip / img_offset as in the forward) - the attention-supervision loss (K4).
  *
  * bwd outputs, consumed by three plain GEMMs on the caller's BLAS:
  *   xout  [n_slots, B_img, S_pad] op dtype   X = ds + alpha*a2 :
@@ -168,8 +170,9 @@ int glr_local_attn_bwd(const void* vt, const void* gram, const void* tp, const f
                        const int32_t* order, const int32_t* tile_nsub, const int32_t* item_tile, int n_items,
                        int n_tiles, int n_sent, int B_img, int D, int S_eff, float temp1, float temp2, float temp3,
                        int agg, float eps, const float* sim, const float* dsim, int ld_sim, const float* lse,
-                       const float* wstat, const float* damean, void* xout, void* aout, float* gamma, float* beta,
-                       int op_dtype, void* stream);
+                       const float* wstat, const float* damean, const float* dattn, const int64_t* attn_off,
+                       int strip, int img_offset, void* xout, void* aout, float* gamma, float* beta, int op_dtype,
+                       void* stream);
 
 /* K-tiling of the K1 operands (device, HBM-bound copy).  glr_local_attn_fwd / _bwd take vt, gram and tp in
  * the K-TILED layout: every block of `rows` rows (vt, gram: the S_pad rows of one image; tp: the 64 slots of one
@@ -258,6 +261,22 @@ int glr_attn_reg_fwd(const float* amean, int B_img, int n_sent, int S_pad, int S
                      float* out, void* stream);
 int glr_attn_reg_bwd(const float* amean, int B_img, int n_sent, int S_pad, int S_eff, int shift, int img_offset,
                      const float* coef, float* damean, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Exact selection on fp32 scores (MSD radix select on the order-preserving bit pattern: the SAME element a
+ * CPU sort picks, bit exact).  Ties rank by DESCENDING index (a reversed stable ascending argsort); -0.0 == +0.0;
+ * NaN ranks above +inf.  rows independent problems of n contiguous floats each, n < 2^32.
+ *   glr_kth_value        out[row] = k-th SMALLEST value (k 1-indexed)
+ *                        == torch.topk(preds, k, largest=False).values.max()   (gloria/lightning/callbacks.py:56)
+ *   glr_topk_desc        idx[row, :k] = np.argsort(x)[::-1][:k]  (gloria/models/retrival_model.py:118), k <= 1024;
+ *                        val (optional) the scores in that order
+ *   glr_threshold_counts out[row] = { #(pred > thr & target), #(pred > thr), #(target), #(pred > thr | target) }:
+ *                        the counts behind precision / recall / F1 / IoU at a percentile threshold (callbacks.py:57-61)
+ */
+int glr_kth_value(const float* x, int rows, long long n, long long k, float* out, void* stream);
+int glr_topk_desc(const float* x, int rows, long long n, int k, int64_t* idx, float* val, void* stream);
+int glr_threshold_counts(const float* pred, const uint8_t* target, const float* thr, int rows, long long n,
+                         uint64_t* out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -93,3 +93,40 @@ def test_attention_supervision_matches_oracle():
     out.backward()
     want = np.concatenate([m.grad.numpy().reshape(-1) for m in maps_ref])
     np.testing.assert_allclose(f.grad.cpu().numpy(), want, rtol=1e-4, atol=1e-8)
+
+
+@pytest.mark.parametrize("dtype,no_attn", [(torch.float32, False), (torch.float32, True), (torch.bfloat16, True)])
+def test_attention_supervision_gradient_through_k1(dtype, no_attn):
+    """The gradient of the attention-supervision loss (gloria_model.py:143-147) reaches the embeddings through the
+    diagonal attention maps: K4 emits d(loss)/d(map), K1 backward takes it as `dattn`.  Checked against autograd
+    through the oracle, alone and mixed with the contrastive terms; one sentence spans several word tiles."""
+    from gloria.datasets.synthetic import make_batch
+    from gloria.loss import gloria_loss as GL
+    from oracle import gloria_oracle as orc
+    import golden_inputs as gi
+    B, D, H, W, L = 6, 768, 19, 19, 97
+    cap_lens = [70, 33, 17, 9, 4, 1]
+    img = torch.from_numpy(gi.normal(611, B, D, H, W)).to(dtype)
+    words = torch.from_numpy(gi.normal(612, B, D, L)).to(dtype)
+    na = torch.from_numpy(gi.normal(613, D, std=1.0)).to(dtype) if no_attn else None
+    labels = make_batch(B, seed=17, segmentation=True)["segmentation_labels"]
+    for w_contrastive in (0.0, 0.3):
+        ti, tw = img.detach().to(DEV).requires_grad_(True), words.detach().to(DEV).requires_grad_(True)
+        tn = None if na is None else na.detach().to(DEV).requires_grad_(True)
+        l0, l1, _, _, _, maps = GL.local_loss(ti, tw, cap_lens, no_attn_vec=tn)
+        seg = GL.attention_supervision_loss(maps, labels.to(DEV))
+        (seg + w_contrastive * (l0 + l1)).backward()
+        ri, rw = img.detach().float().clone().requires_grad_(True), words.detach().float().clone().requires_grad_(True)
+        rn = None if na is None else na.detach().float().clone().requires_grad_(True)
+        r = orc.local_loss(ri, rw, cap_lens, no_attn_vec=rn)
+        segr = orc.attention_supervision_loss(r[5], labels, 1.0)
+        (segr + w_contrastive * (r[0] + r[1])).backward()
+        f32 = dtype == torch.float32
+        np.testing.assert_allclose(float(seg.detach()), float(segr), rtol=1e-4 if f32 else 2e-2)
+        pairs = [(ti.grad, ri.grad), (tw.grad, rw.grad)] + ([] if tn is None else [(tn.grad, rn.grad)])
+        for a, b in pairs:
+            a, b = a.float().cpu().numpy(), b.numpy()
+            if f32:
+                np.testing.assert_allclose(a, b, rtol=2e-3, atol=1e-6)
+            else:
+                assert np.linalg.norm(a - b) / np.linalg.norm(b) < 0.05
