@@ -278,6 +278,25 @@ int glr_topk_desc(const float* x, int rows, long long n, int k, int64_t* idx, fl
 int glr_threshold_counts(const float* pred, const uint8_t* target, const float* thr, int rows, long long n,
                          uint64_t* out, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Fused training-mode BatchNorm2d (+ residual add) (+ ReLU) on channels-last bf16 activations: the bottleneck
+ * epilogues of the ResNet-50 image encoder (reference: torchvision resnet50 through gloria/models/cnn_backbones.py:31-35,
+ * vision_model.py:67-86).  x / y / dy / dx / residual: bf16 [R = N*H*W, C] (NHWC memory), C % 8 == 0.
+ *   fwd   mean, invstd [C] out (batch statistics, biased variance + eps); run_mean / run_var updated with
+ *         `momentum` and the unbiased variance like nn.BatchNorm2d (NULL = no running statistics);
+ *         y = relu?( (x - mean) invstd gamma + beta (+ residual) )
+ *   bwd   dx, dgamma, dbeta; with a residual also dres = dy * [y > 0] (gradient of the skip branch)
+ *   workspace: glr_bn_workspace_floats(R, C) floats; tmp2c: 2 * C floats.
+ * HBM-bound; fixed-order two-level reductions (bitwise reproducible).
+ */
+int glr_bn_workspace_floats(long long R, int C);
+int glr_bn_act_fwd(const void* x, const void* residual, const float* gamma, const float* beta, long long R, int C,
+                   float eps, float momentum, int relu, float* run_mean, float* run_var, float* mean, float* invstd,
+                   float* workspace, void* y, void* stream);
+int glr_bn_act_bwd(const void* x, const void* dy, const void* y, const float* gamma, const float* beta, const float* mean,
+                   const float* invstd, long long R, int C, int relu, int has_residual, float* workspace, float* dgamma,
+                   float* dbeta, float* tmp2c, void* dx, void* dres, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
