@@ -159,17 +159,14 @@ constexpr int PD = 3;       // chunks issued ahead of the one being consumed
 // buffer is the target of the DMA for chunk c+PD issued right after the barrier.
 // Measured (tools/stamps_k1.py): the streams run at ~27 B/clk/CU of L2->LDS DMA issue, independent of the
 // prefetch depth and of reading fragments one chunk ahead; fewer DMA-issuing waves are slower.
-template <typename O, bool A_RES, int NPWC, int NH = 1, int NB = NBUF, int CB = CHB>
+template <typename O, bool A_RES, int NPWC, int NH = 1, int NB = NBUF>
 __device__ __forceinline__ void stream_gemm_n(f32x16 (&acc)[3], f32x16 (&acc2)[3], int img2_off, unsigned char* ring,
                                               int buf_bytes,
                                               const unsigned char* asrc, size_t apitch,
                                               const unsigned char* bsrc, size_t bpitch, int brows, int nchunk,
                                               const unsigned char* aimg, int aimg_pitch, int wave, int lane, int wm,
                                               int wg, int nrb, int tw) {
-  // CB = bytes of K per ring row: CHB (64) or 2 * CHB (128: half the barriers per K, 2-deep ring only).  The HBM
-  // tiling stays CHB wide, so a 128-byte row is two 64-byte runs that lie `rows * CHB` bytes apart.
-  constexpr int PPR = CB / 16, RPB = 256 / CB, KSTEPS = CB / 32, RPI = 64 / PPR, SUB = CB / CHB;
-  static_assert(CB == CHB || CB == 2 * CHB, "chunk width");
+  constexpr int PPR = CHB / 16, RPB = 256 / CHB, KSTEPS = CHB / 32, RPI = 64 / PPR;
   constexpr int PDD = NB - 1;                          // chunks issued ahead; buffer (c+PDD) % NB == (c-1) % NB
   constexpr bool STAG = GLR_STAGGER && PDD == 3;
   static_assert(PDD == 1 || PDD == 3, "wait immediates are written for 2- and 4-deep rings");
@@ -192,7 +189,7 @@ __device__ __forceinline__ void stream_gemm_n(f32x16 (&acc)[3], f32x16 (&acc2)[3
   // to load / wait / MFMA in its own basic block and serialises on the LDS latency)
   int bofs[3];
 #pragma unroll
-  for (int j = 0; j < 3; ++j) bofs[j] = (arows + min(wg + 4 * j, nrb - 1) * 32 + l31) * CB;
+  for (int j = 0; j < 3; ++j) bofs[j] = (arows + min(wg + 4 * j, nrb - 1) * 32 + l31) * CHB;
 
   // every wave issues exactly NPWC pieces per chunk (piece indices past the end are clamped to the
   // last piece: two waves then write the same bytes to the same LDS slot, which is harmless)
@@ -210,12 +207,9 @@ __device__ __forceinline__ void stream_gemm_n(f32x16 (&acc)[3], f32x16 (&acc2)[3
     // A row r of the ring = populated row (r % tw) of tile (r / tw); a tile block holds TW rows per chunk.
     const bool is_a = row < arows;
     const int tl = row / tw, rr = row - tl * tw;
-    const int sub = g / (CHB / 16), g16 = g % (CHB / 16);    // 64-byte run of the row this lane's 16 bytes lie in
-    const int blk_rows = is_a ? TW : brows;
-    const size_t off = (is_a ? (size_t)tl * TW * apitch + (size_t)rr * CHB : (size_t)(row - arows) * CHB) +
-                       (size_t)sub * blk_rows * CHB;
-    psrc[i] = (is_a ? asrc : bsrc) + off + g16 * 16;
-    pstep[i] = SUB * blk_rows * CHB;                         // bytes from one ring chunk to the next
+    const size_t off = is_a ? (size_t)tl * TW * apitch + (size_t)rr * CHB : (size_t)(row - arows) * CHB;
+    psrc[i] = (is_a ? asrc : bsrc) + off + g * 16;
+    pstep[i] = (is_a ? TW : brows) * CHB;                    // bytes from one K chunk to the next
     pdst[i] = ring_lds + k * 1024;
   }
   auto issue = [&](int c) {
@@ -226,13 +220,13 @@ __device__ __forceinline__ void stream_gemm_n(f32x16 (&acc)[3], f32x16 (&acc2)[3
   auto compute = [&](int c) {
     const unsigned char* rb = ring + (c % NB) * buf_bytes;
     if (active) {
-      const unsigned char* aa0 = A_RES ? (aimg + (wm * 32 + l31) * aimg_pitch + c * CB + h * 16)
-                                       : (rb + (wm * 32 + l31) * CB);
+      const unsigned char* aa0 = A_RES ? (aimg + (wm * 32 + l31) * aimg_pitch + c * CHB + h * 16)
+                                       : (rb + (wm * 32 + l31) * CHB);
       typename O::frag fa[KSTEPS], fa2[KSTEPS], fb[KSTEPS][3];
 #pragma unroll
       for (int kk = 0; kk < KSTEPS; ++kk) {
         fa[kk] = A_RES ? O::ld(aa0 + kk * 32) : O::ld(aa0 + koff[kk]);
-        if (NH == 2) fa2[kk] = A_RES ? O::ld(aa0 + img2_off + kk * 32) : O::ld(aa0 + tw * CB + koff[kk]);
+        if (NH == 2) fa2[kk] = A_RES ? O::ld(aa0 + img2_off + kk * 32) : O::ld(aa0 + tw * CHB + koff[kk]);
 #pragma unroll
         for (int j = 0; j < 3; ++j) fb[kk][j] = O::ld(rb + bofs[j] + koff[kk]);
       }
@@ -271,30 +265,22 @@ __device__ __forceinline__ void stream_gemm_n(f32x16 (&acc)[3], f32x16 (&acc2)[3
   wg_barrier();                                          // every wave is done with the ring
 }
 
-template <typename O, bool A_RES, int NH = 1, int NB = NBUF, int CB = CHB>
+template <typename O, bool A_RES, int NH = 1, int NB = NBUF>
 __device__ __forceinline__ void stream_gemm(f32x16 (&acc)[3], f32x16 (&acc2)[3], int img2_off, unsigned char* ring,
                                             int buf_bytes, const unsigned char* asrc, size_t apitch,
                                             const unsigned char* bsrc, size_t bpitch, int brows, int nchunk,
                                             const unsigned char* aimg, int aimg_pitch, int wave, int lane, int wm,
                                             int wg, int nrb, int tw) {
-  constexpr int RPI = 64 / (CB / 16);
+  constexpr int RPI = 64 / (CHB / 16);
   const int winstr = ((A_RES ? 0 : NH * tw) + brows) / RPI;
   const int npw = (winstr + 7) / 8;                      // workgroup-uniform
-#define GLR_SG(N) stream_gemm_n<O, A_RES, N, NH, NB, CB>(acc, acc2, img2_off, ring, buf_bytes, asrc, apitch, bsrc, bpitch, brows, \
+#define GLR_SG(N) stream_gemm_n<O, A_RES, N, NH, NB>(acc, acc2, img2_off, ring, buf_bytes, asrc, apitch, bsrc, bpitch, brows, \
                                                  nchunk, aimg, aimg_pitch, wave, lane, wm, wg, nrb, tw)
-  if constexpr (CB == CHB) {
-    switch (npw) {
-      case 1: GLR_SG(1); break;
-      case 2: GLR_SG(2); break;
-      case 3: GLR_SG(3); break;
-      default: GLR_SG(4); break;
-    }
-  } else {                                               // 128-byte chunks: 8-row pieces, twice as many
-    switch (npw) {
-      case 6: GLR_SG(6); break;
-      case 7: GLR_SG(7); break;
-      default: GLR_SG(8); break;
-    }
+  switch (npw) {
+    case 1: GLR_SG(1); break;
+    case 2: GLR_SG(2); break;
+    case 3: GLR_SG(3); break;
+    default: GLR_SG(4); break;
   }
 #undef GLR_SG
 }
@@ -921,11 +907,8 @@ __global__ void __launch_bounds__(NTHR) k_local_attn_pair(LaParams p) {
     for (int q = 0; q < 16; ++q) { accA[j][q] = 0.f; accB[j][q] = 0.f; }
   __syncthreads();
   GLR_STAMP2(1);
-  // 128-byte-K chunks in a 2-deep ring (same 128 KiB of LDS as four 64-byte chunks): 12 barriers instead of 24
-  // for K = 768, 48 MFMAs per SIMD between two barriers while the next 64 KiB chunk streams in
-  stream_gemm<O, false, 2, 2, 2 * CHB>(accA, accB, 0, ring, (2 * TW + SP) * 2 * CB, p.tp + (size_t)tile0 * TW * rowbytes1,
-                                       rowbytes1, vt_b, rowbytes1, SP, (int)(rowbytes1 / (2 * CB)), nullptr, 0, wave, lane,
-                                       wm, wg, NRB, TW);
+  stream_gemm<O, false, 2>(accA, accB, 0, ring, (2 * TW + SP) * CB, p.tp + (size_t)tile0 * TW * rowbytes1, rowbytes1,
+                           vt_b, rowbytes1, SP, (int)(rowbytes1 / CB), nullptr, 0, wave, lane, wm, wg, NRB, TW);
   GLR_STAMP2(2);
 
   // ================= word-softmax statistics from the scores in registers =================
