@@ -131,7 +131,11 @@ class GradReducer:
         off, idx = 0, len(self.buckets)
         for p in plist:
             n = p.numel()
-            p.grad = flat[off:off + n].view_as(p)
+            # the view gets the parameter's own strides (channels-last conv weights, incl. the ambiguous 1x1 case):
+            # fused Adam requires params and grads with identical strides, and autograd's layout contract
+            # then accumulates in place without a copy.  Parameters are dense, so n elements cover the view.
+            p.grad = flat.as_strided(p.shape, p.stride(), storage_offset=off)
+            assert p.grad.stride() == p.stride() and p.grad.numel() == n
             off += n
             p.register_post_accumulate_grad_hook(lambda _p, i=idx: self._on_ready(i))
         self.buckets.append((flat, plist))

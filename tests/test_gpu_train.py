@@ -99,3 +99,38 @@ def test_attention_finetune_config_runs():
     assert np.isfinite(l0)
     g = [p.grad for p in model.gloria.img_encoder.local_embedder.parameters()]
     assert g[0] is not None and float(g[0].abs().sum()) > 0
+
+
+def test_data_parallel_path_single_rank_rehearsal(monkeypatch):
+    """The code path the 2/4/8-GPU runs take (text all-gather, block-row similarity, bucketed gradient reducer with
+    gradients as views of flat buckets, global-norm clip, fused Adam on channels-last parameters), rehearsed on
+    one GPU with a single-rank RCCL group: two bf16 steps must run and agree with the plain single-GPU step."""
+    import socket
+    import torch.distributed as dist
+    from gloria import builder, dist as gdist
+    from gloria.config import pretrain_config
+    from gloria.datasets.synthetic import make_batch
+    from gloria.trainer import Trainer
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    for k, v in dict(GLR_FORCE_DIST="1", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+                     MASTER_PORT=str(port)).items():
+        monkeypatch.setenv(k, v)
+    B = 8
+    cfg = pretrain_config("imagenome", batch_size=B)
+    cfg.set_path("model.text.bert_config", dict(num_hidden_layers=2, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0))
+    batch = make_batch(B, seed=3)
+    losses = {}
+    try:
+        for mode in ("plain", "dist"):
+            torch.manual_seed(11)
+            model = builder.build_lightning_model(cfg, builder.build_data_module(cfg))
+            dctx = gdist.init_from_env("nccl") if mode == "dist" else None
+            tr = Trainer(cfg, device="cuda:0", precision="bf16", dist_ctx=dctx)
+            tr.setup(model)
+            model.train()
+            losses[mode] = [float(tr.training_step(model, batch, i)) for i in range(2)]
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+    assert all(np.isfinite(losses["dist"]))
+    np.testing.assert_allclose(losses["dist"], losses["plain"], rtol=2e-2)
