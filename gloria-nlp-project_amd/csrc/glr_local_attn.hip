@@ -99,6 +99,17 @@ struct LaParams {
 };
 
 #ifdef GLR_STAMPS
+// per-wave stamps inside the P1 stream of the pair kernel: [workgroup][wave][chunk][3] = after the barrier,
+// after the DMA issue, after the MFMAs (tools/stamps_k1.py waves)
+__device__ unsigned long long* g_wave_stamps = nullptr;
+#define GLR_WSTAMP(c, k)                                                                               \
+  do {                                                                                                 \
+    if (NH == 2 && !A_RES && g_wave_stamps != nullptr && (lane == 0) && blockIdx.x < 4096) {            \
+      unsigned long long t_;                                                                           \
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                       \
+      g_wave_stamps[(((size_t)blockIdx.x * 8 + wave) * 32 + (c)) * 3 + (k)] = t_;                       \
+    }                                                                                                  \
+  } while (0)
 #define GLR_STAMP(i)                                                                        \
   do {                                                                                      \
     if (tid == 0 && p.stamps) {                                                             \
@@ -118,6 +129,7 @@ struct LaParams {
 #else
 #define GLR_STAMP(i)
 #define GLR_STAMP2(i)
+#define GLR_WSTAMP(c, k)
 #endif
 
 __device__ __forceinline__ unsigned lds_addr(const void* p) {
@@ -253,9 +265,12 @@ __device__ __forceinline__ void stream_gemm_n(f32x16 (&acc)[3], f32x16 (&acc2)[3
   for (; c + PDD <= nchunk; ++c) {                       // steady state: PDD-1 younger chunks stay in flight
     wait_vm<(PDD - 1) * NPWC>();
     wg_barrier();
+    GLR_WSTAMP(c, 0);
     if (!late && c + PDD < nchunk) issue(c + PDD);
+    GLR_WSTAMP(c, 1);
     compute(c);
     if (late && c + PDD < nchunk) issue(c + PDD);
+    GLR_WSTAMP(c, 2);
   }
   for (; c < nchunk; ++c) {                              // tail (PDD == 3 only): nchunk-1-c younger chunks in flight
     if (nchunk - 1 - c == 1) wait_vm<NPWC>(); else wait_vm<0>();
@@ -1304,4 +1319,8 @@ extern "C" int glr_local_attn_bwd(const void* vt, const void* gram, const void* 
 // diagnostic build only: device buffer of [grid][12] u64 receiving s_memtime stamps of every K1 launch
 extern "C" void glr_debug_set_stamps(void* buf) { g_stamps = (unsigned long long*)buf; }
 extern "C" void glr_debug_set_stamps_pair(void* buf) { g_stamps2 = (unsigned long long*)buf; }
+extern "C" void glr_debug_set_wave_stamps(void* buf) {
+  unsigned long long* v = (unsigned long long*)buf;
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_wave_stamps), &v, sizeof(v));
+}
 #endif

@@ -29,6 +29,24 @@ L.glr_debug_set_stamps_pair.argtypes = [ctypes.c_void_p]
 L.glr_debug_set_stamps(ctypes.c_void_p(buf.data_ptr()))
 L.glr_debug_set_stamps_pair(ctypes.c_void_p(buf2.data_ptr()))
 run(); torch.cuda.synchronize()
+if len(sys.argv) > 1 and sys.argv[1] == "waves":
+    # per-wave view of the P1 stream of the pair kernel (first 4096 workgroups)
+    wbuf = torch.zeros(4096 * 8 * 32 * 3, dtype=torch.int64, device=dev)
+    L.glr_debug_set_wave_stamps.argtypes = [ctypes.c_void_p]
+    L.glr_debug_set_wave_stamps(ctypes.c_void_p(wbuf.data_ptr()))
+    run(); torch.cuda.synchronize()
+    w = wbuf.cpu().numpy().reshape(4096, 8, 32, 3).astype(np.float64)
+    ok = w[:, 0, 5, 0] > 0
+    w = w[ok][:, :, :24]                      # 24 chunks
+    dma = w[:, :, 4:20, 1] - w[:, :, 4:20, 0]
+    comp = w[:, :, 4:20, 2] - w[:, :, 4:20, 1]
+    wait = w[:, :, 5:21, 0] - w[:, :, 4:20, 2]
+    period = w[:, :, 5:21, 0] - w[:, :, 4:20, 0]
+    print(f"workgroups {ok.sum()}; per chunk, median over workgroups and chunks 4..19 (cycles)")
+    print("wave   DMA-issue  reads+MFMA  wait(vmcnt+barrier)  period")
+    for wv in range(8):
+        print(f"  {wv}   {np.median(dma[:, wv]):9.0f}  {np.median(comp[:, wv]):10.0f}  {np.median(wait[:, wv]):19.0f}  {np.median(period[:, wv]):6.0f}")
+    sys.exit(0)
 if not bwd:
     s2 = buf2.cpu().numpy().reshape(grid, 12)
     s2 = s2[s2[:, 0] > 0]
