@@ -12,7 +12,8 @@ import torch
 
 
 class Trainer:
-    def __init__(self, cfg, device="cuda", precision=None, dist_ctx=None, log_path=None, miopen_benchmark=False):
+    def __init__(self, cfg, device="cuda", precision=None, dist_ctx=None, log_path=None, miopen_benchmark=False,
+                 sync_bn=False):
         self.cfg = cfg
         self.device = torch.device(device)
         prec = precision if precision is not None else cfg.lightning.trainer.precision
@@ -27,6 +28,10 @@ class Trainer:
         # but searches for minutes on a cold find-db; bench.py turns it on only with the tuned db shipped
         # under gloria-nlp-project_amd/miopen_db (see gloria.miopen_db)
         self.miopen_benchmark = miopen_benchmark
+        # data-parallel parity mode: BatchNorm statistics over the GLOBAL batch (torch SyncBatchNorm: one small
+        # per-channel all-reduce per layer) - the reference oracle is single-device full-batch BN (SURVEY.md
+        # section 7); the default keeps per-rank statistics (speed mode)
+        self.sync_bn = bool(sync_bn)
 
     # ------------------------------------------------------------------ setup
     def setup(self, model):
@@ -35,6 +40,9 @@ class Trainer:
             torch.backends.cudnn.benchmark = bool(self.miopen_benchmark)
             model.gloria.img_encoder.to(memory_format=torch.channels_last)
         model.gloria.dist = self.dist
+        if self.sync_bn and self.dist is not None and self.dist.world_size > 1:
+            model.gloria.img_encoder = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model.gloria.img_encoder,
+                                                                                      self.dist.group)
         opt = model.configure_optimizers()
         self.optimizer, self.scheduler = opt["optimizer"], opt["lr_scheduler"]
         self.params = [p for g in self.optimizer.param_groups for p in g["params"]]
