@@ -127,9 +127,18 @@ __global__ void __launch_bounds__(256) k_global_bwd(const float* __restrict__ X,
   __syncthreads();
   const float cself = part[0] + part[1] + part[2] + part[3];
   for (int d = threadIdx.x; d < D; d += 256) {
-    float acc = 0.f;
-    for (int j = 0; j < n_other; ++j) acc += coef[j] * Y[(size_t)j * D + d];
-    dX[(size_t)a * D + d] = acc - cself * X[(size_t)a * D + d];
+    // four independent chains (the loop is latency bound: one dependent FMA per L2 load otherwise), summed in a
+    // fixed order
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int j = 0;
+    for (; j + 4 <= n_other; j += 4) {
+      a0 += coef[j] * Y[(size_t)j * D + d];
+      a1 += coef[j + 1] * Y[(size_t)(j + 1) * D + d];
+      a2 += coef[j + 2] * Y[(size_t)(j + 2) * D + d];
+      a3 += coef[j + 3] * Y[(size_t)(j + 3) * D + d];
+    }
+    for (; j < n_other; ++j) a0 += coef[j] * Y[(size_t)j * D + d];
+    dX[(size_t)a * D + d] = ((a0 + a1) + (a2 + a3)) - cself * X[(size_t)a * D + d];
   }
 }
 
