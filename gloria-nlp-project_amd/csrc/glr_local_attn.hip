@@ -1025,7 +1025,9 @@ __global__ void __launch_bounds__(NTHR) k_local_attn_pair(LaParams p) {
   float okr[3];
 #pragma unroll
   for (int j = 0; j < 3; ++j) okr[j] = (rbase + 128 * j < p.S_eff) ? 1.f : 0.f;
-  auto p2 = [&](f32x16 (&acc)[3], const int (&pk)[4], int t) {
+  // the bf16-rounded e2 of both tiles stay in registers (two per dword) for the |c|^2 sums of P4
+  unsigned e2A[3][8], e2B[3][8];
+  auto p2 = [&](f32x16 (&acc)[3], const int (&pk)[4], int t, unsigned (&e2k)[3][8]) {
     unsigned char* imgw = img0 + t * IMG + (wm * 32 + 4 * h) * IMP + rbase * ESZ;   // + row(q) * IMP + 128 * j * ESZ
     float* redt = red + t * 16 * TW + rslot * TW + wm * 32 + 4 * h;               // + 8 * TW (dot) + row(q)
     float nx[3];
@@ -1052,6 +1054,8 @@ __global__ void __launch_bounds__(NTHR) k_local_attn_pair(LaParams p) {
         const float e2 = __builtin_amdgcn_exp2f(t1l * a1);
         O::from_f32(imgw + row * IMP + 128 * j * ESZ, e2);
         const float e2r = ESZ == 4 ? e2 : bf2f(f2bf(e2));
+        const unsigned eb = __float_as_uint(e2r);                        // low 16 bits are zero
+        e2k[j][q >> 1] = (q & 1) ? (e2k[j][q >> 1] | eb) : (eb >> 16);
         zacc = __builtin_fmaf(e2r, okr[j], zacc);
         dacc = __builtin_fmaf(e2r, acc[j][q], dacc);
         acc[j][q] = 0.f;
@@ -1065,8 +1069,8 @@ __global__ void __launch_bounds__(NTHR) k_local_attn_pair(LaParams p) {
   };
   // NB: the images alias the mx / ps tables, dead now; the lse tables live above the images until the
   // barrier below, then the P3 ring takes their place
-  p2(accA, sgA, 0);
-  p2(accB, sgB, 1);
+  p2(accA, sgA, 0, e2A);
+  p2(accB, sgB, 1, e2B);
   __syncthreads();
   if (tid < 2 * TW) {
     const float* redt = red + (tid >> 6) * 16 * TW + (tid & 63);
@@ -1084,21 +1088,23 @@ __global__ void __launch_bounds__(NTHR) k_local_attn_pair(LaParams p) {
   GLR_STAMP2(6);
 
   // ================= P4: |c|^2, cosine, per-sentence aggregate, diagonal attention maps =================
-  auto p4 = [&](f32x16 (&acc)[3], int t) {
-    const unsigned char* imgw = img0 + t * IMG + (wm * 32 + 4 * h) * IMP + rbase * ESZ;
+  auto p4 = [&](f32x16 (&acc)[3], int t, const unsigned (&e2k)[3][8]) {
     float* redt = red + t * 16 * TW + rslot * TW + wm * 32 + 4 * h;
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
       const int row = (q & 3) + 8 * (q >> 2);
       float v = 0.f;
 #pragma unroll
-      for (int j = 0; j < 3; ++j) v += O::to_f32(imgw + row * IMP + 128 * j * ESZ) * acc[j][q];
+      for (int j = 0; j < 3; ++j) {
+        const unsigned u = e2k[j][q >> 1];
+        v += __uint_as_float((q & 1) ? (u & 0xffff0000u) : (u << 16)) * acc[j][q];
+      }
       v = row_sum16(v);
       if ((lane & 15) == 15) redt[row] = v;
     }
   };
-  p4(accA, 0);
-  p4(accB, 1);
+  p4(accA, 0, e2A);
+  p4(accB, 1, e2B);
   __syncthreads();
   GLR_STAMP2(7);
   if (tid < 2 * TW) {            // waves 0 / 1 = tile A / B, lane = word slot
