@@ -1004,14 +1004,12 @@ __global__ void __launch_bounds__(NTHR) k_local_attn_pair(LaParams p) {
   run_sum(accA, sgA);
   run_sum(accB, sgB);
   __syncthreads();
-  if (tid < SP) {
-    for (int s2 = 0; s2 < NS; ++s2) {
-      const float sum = (ps[s2 * SP + tid] + ps[(PAIR_MAXSEG + s2) * SP + tid]) +
-                        (ps[(2 * PAIR_MAXSEG + s2) * SP + tid] + ps[(3 * PAIR_MAXSEG + s2) * SP + tid]);
-      const float l2 = mx[s2 * SP + tid] + __builtin_amdgcn_logf(sum);      // v_log_f32 = log2
-      tab[s2 * SP + tid] = l2;
-      if (p.lse) p.lse[((size_t)b * p.n_sent + seg_sent[s2]) * SP + tid] = l2 * LN2;
-    }
+  for (int i = tid; i < NS * SP; i += NTHR) {          // all 512 threads, independent entries
+    const int s2 = i / SP, r = i - s2 * SP;
+    const float sum = (ps[i] + ps[PAIR_MAXSEG * SP + i]) + (ps[2 * PAIR_MAXSEG * SP + i] + ps[3 * PAIR_MAXSEG * SP + i]);
+    const float l2 = mx[i] + __builtin_amdgcn_logf(sum);      // v_log_f32 = log2
+    tab[i] = l2;
+    if (p.lse) p.lse[((size_t)b * p.n_sent + seg_sent[s2]) * SP + r] = l2 * LN2;
   }
   __syncthreads();
   GLR_STAMP2(4);
