@@ -895,9 +895,12 @@ __global__ void __launch_bounds__(NTHR) k_local_attn_pair(LaParams p) {
     tnl[tid] = p.tnorm[(size_t)tile0 * TW + tid];
   }
   if (tid < 3) misc[tid] = 0;
+  // a pair is either two ordinary tiles or ONE sentence of 65..128 words that owns both tiles (the planner lists
+  // it once per tile): a single segment spanning tile A and B
+  const bool long_pair = p.tile_nsub[tile0] == 2;
   {
     const int sf0 = p.tile_first[tile0], sf2 = p.tile_first[tile0 + 2];
-    const int ns = sf2 - sf0;
+    const int ns = long_pair ? 1 : sf2 - sf0;
     if (tid == 0) misc[0] = ns;
     if (tid < ns) {
       const int sent = p.order[sf0 + tid];
@@ -927,10 +930,11 @@ __global__ void __launch_bounds__(NTHR) k_local_attn_pair(LaParams p) {
   GLR_STAMP2(2);
 
   // ================= word-softmax statistics from the scores in registers =================
+  // partial-sum tables: one per (word block, half wave) - and per tile for the spanning sentence of a long pair
+  const int n_ps = long_pair ? 8 : 4, ps_stride = long_pair ? SP : PAIR_MAXSEG * SP;
   for (int i = tid; i < NS * SP; i += NTHR) {
     mx[i] = -INFINITY;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) ps[k * PAIR_MAXSEG * SP + i] = 0.f;
+    for (int k = 0; k < n_ps; ++k) ps[k * ps_stride + i] = 0.f;
   }
   // sentence ids of this lane's 16 word rows of tile t: word = wm*32 + (q&3) + 8*(q>>2) + 4*h, so the four
   // rows of a q-group are four consecutive bytes
@@ -970,8 +974,8 @@ __global__ void __launch_bounds__(NTHR) k_local_attn_pair(LaParams p) {
   // independent LDS read per element: no serial dependence on the run bookkeeping)
   // (LDS float-add atomics measured ~60 cycles per wave instruction here; every (word block, half wave,
   //  sentence, region) has exactly one writer, so plain stores into four partial tables do the same job)
-  float* psw = ps + (wm * 2 + h) * PAIR_MAXSEG * SP;
-  auto run_sum = [&](f32x16 (&acc)[3], const int (&pk)[4]) {
+  auto run_sum = [&](f32x16 (&acc)[3], const int (&pk)[4], int t) {
+    float* psw = ps + ((long_pair ? 4 * t : 0) + wm * 2 + h) * ps_stride;
     float rs[3] = {0.f, 0.f, 0.f}, nx[3];
     {
       const float* src = mx + max(GLR_SGQ(pk, 0), 0) * SP + rbase;
@@ -1001,12 +1005,13 @@ __global__ void __launch_bounds__(NTHR) k_local_attn_pair(LaParams p) {
       for (int j = 0; j < 3; ++j) rs[j] = last ? 0.f : rs[j];
     }
   };
-  run_sum(accA, sgA);
-  run_sum(accB, sgB);
+  run_sum(accA, sgA, 0);
+  run_sum(accB, sgB, 1);
   __syncthreads();
   for (int i = tid; i < NS * SP; i += NTHR) {          // all 512 threads, independent entries
     const int s2 = i / SP, r = i - s2 * SP;
-    const float sum = (ps[i] + ps[PAIR_MAXSEG * SP + i]) + (ps[2 * PAIR_MAXSEG * SP + i] + ps[3 * PAIR_MAXSEG * SP + i]);
+    float sum = (ps[i] + ps[ps_stride + i]) + (ps[2 * ps_stride + i] + ps[3 * ps_stride + i]);
+    if (long_pair) sum += (ps[4 * ps_stride + i] + ps[5 * ps_stride + i]) + (ps[6 * ps_stride + i] + ps[7 * ps_stride + i]);
     const float l2 = mx[i] + __builtin_amdgcn_logf(sum);      // v_log_f32 = log2
     tab[i] = l2;
     if (p.lse) p.lse[((size_t)b * p.n_sent + seg_sent[s2]) * SP + r] = l2 * LN2;
@@ -1134,8 +1139,21 @@ __global__ void __launch_bounds__(NTHR) k_local_attn_pair(LaParams p) {
     }
     const int snext = __shfl_down(sg, 1, 64);
     if (sg >= 0 && (lane == 63 || snext != sg)) {
-      if (p.agg == GLR_AGG_MEAN) v /= (float)seg_n[sg];
-      p.sim[(size_t)b * p.ld_sim + seg_sent[sg]] = p.temp3 * __logf(v);
+      if (long_pair) {
+        reinterpret_cast<float*>(misc)[8 + wave] = v;      // this tile's part of the spanning sentence
+      } else {
+        if (p.agg == GLR_AGG_MEAN) v /= (float)seg_n[sg];
+        p.sim[(size_t)b * p.ld_sim + seg_sent[sg]] = p.temp3 * __logf(v);
+      }
+    }
+  }
+  if (long_pair) {
+    __syncthreads();
+    if (tid == 0) {
+      const float* part = reinterpret_cast<const float*>(misc) + 8;
+      float v = (p.agg == GLR_AGG_MAX) ? fmaxf(part[0], part[1]) : part[0] + part[1];
+      if (p.agg == GLR_AGG_MEAN) v /= (float)seg_n[0];
+      p.sim[(size_t)b * p.ld_sim + seg_sent[0]] = p.temp3 * __logf(v);
     }
   }
   const int dw0 = misc[1], dn = misc[2];

@@ -68,7 +68,10 @@ extern "C" int glr_plan_items(const int32_t* tile_nsub, const int32_t* tile_firs
   auto pairable = [&](int t) { return t < n_tiles && tile_nsub[t] == 0; };
   for (int t = 0; t < n_tiles;) {
     if (tile_nsub[t] < 0) return GLR_EINVAL;         // a continuation tile cannot start an item
-    if (tile_nsub[t] > 1) {                          // multi-tile sentence: one item, handled in sweeps
+    if (tile_nsub[t] == 2 && allow_pairs) {          // a 65..128-word sentence owns exactly one pair of tiles
+      pair_tile[np++] = t; all_tile[na++] = t;       // forward: pair kernel; backward: multi-tile path of the head
+      t += 2;
+    } else if (tile_nsub[t] > 1) {                   // longer sentence: one item, handled in sweeps
       single_tile[ns++] = t; all_tile[na++] = t;
       t += tile_nsub[t];
     } else if (allow_pairs && pairable(t) && pairable(t + 1) && tile_first[t + 2] - tile_first[t] <= max_pair_seg) {

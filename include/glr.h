@@ -82,7 +82,7 @@ int glr_plan_tiles(const int32_t* cap_lens, int n_sent, int capacity, int32_t* s
  * at most max_pair_seg (16) sentences IN TOTAL become ONE forward work item: a workgroup then streams vt[b] and
  * gram[b] once for 128 words (the streams are the bound).  Outputs (each must hold n_tiles ints):
  *   single_tile  first tile of every un-paired item (ordinary tile or head of a multi-tile sentence)
- *   pair_tile    first tile of every pair
+ *   pair_tile    first tile of every pair: two ordinary tiles, or the two tiles owned by ONE sentence of 65..128 words
  *   all_tile     every item-head tile with pairs expanded (the backward kernel works tile by tile)
  *   counts[3]    number of entries of the three lists
  */

@@ -71,8 +71,11 @@ def test_plan_items_pairing():
     tf = p.tile_first.numpy()
     covered = []
     for t in pairs:
-        assert nsub[t] == 0 and nsub[t + 1] == 0
-        assert tf[t + 2] - tf[t] <= 16                                         # a pair holds <= 16 sentences
+        if nsub[t] == 2:                                                       # one 65..128-word sentence owns the pair
+            assert nsub[t + 1] == -1
+        else:
+            assert nsub[t] == 0 and nsub[t + 1] == 0
+            assert tf[t + 2] - tf[t] <= 16                                     # a pair holds <= 16 sentences
         covered += [t, t + 1]
     for t in singles:
         covered += list(range(t, t + max(nsub[t], 1)))
