@@ -318,7 +318,10 @@ __device__ __forceinline__ float row_sum16(float v) {
 // blocks, so the per-block guards vanish at compile time (a guarded LDS access compiles to its own basic
 // block with a full s_waitcnt: 48 serialised LDS round trips per phase otherwise).
 #define GLR_BLK_OK(blk) (FULL || (blk) < nrb)
-template <typename O, bool BWD, bool FULL>
+// AUX (backward only): extra gradient inputs - `damean` (word-mean attention rows, regularisers) and `dattn`
+// (diagonal attention maps, attention supervision).  A separate instance: their live values cost the plain
+// backward ~90 spilled registers (3.0 -> 5.5 ms) when compiled in unconditionally.
+template <typename O, bool BWD, bool FULL, bool AUX>
 __global__ void __launch_bounds__(NTHR) k_local_attn(LaParams p) {
   constexpr int ESZ = O::ESZ, CB = CHB;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -531,7 +534,7 @@ __global__ void __launch_bounds__(NTHR) k_local_attn(LaParams p) {
       float lcur[3] = {0.f, 0.f, 0.f};
       float gcur[3] = {0.f, 0.f, 0.f};     // bwd: gradient of the word-mean attention row / words in the sentence
       // bwd: gradient of the attention map of the diagonal pair (attention-supervision loss), per (word, region)
-      const bool has_dmap = BWD && p.dattn != nullptr;
+      const bool has_dmap = BWD && AUX && p.dattn != nullptr;
       const int dw0 = has_dmap ? diag[0] : 0, dn = has_dmap ? diag[1] : 0;
       const int sout = p.S_eff - p.strip;
       const float* dmap = has_dmap ? p.dattn + p.attn_off[p.img_offset + b] + (size_t)wbase * sout - p.strip : nullptr;
@@ -551,7 +554,7 @@ __global__ void __launch_bounds__(NTHR) k_local_attn(LaParams p) {
             const int region = min((wg + 4 * j) * 32 + l31, S_pad - 1);
             if (BWD) {
               lcur[j] = p.lse[((size_t)b * p.n_sent + sent) * S_pad + region];
-              if (p.damean != nullptr) gcur[j] = p.damean[((size_t)b * p.n_sent + sent) * S_pad + region] * ninv;
+              if (AUX && p.damean != nullptr) gcur[j] = p.damean[((size_t)b * p.n_sent + sent) * S_pad + region] * ninv;
             } else {
               lcur[j] = (nsub > 1) ? mrun[region] : sc[sg * SCP + region];
             }
@@ -570,12 +573,16 @@ __global__ void __launch_bounds__(NTHR) k_local_attn(LaParams p) {
             if (BWD) {
               // da2 = (alpha s - beta u) + g: the accumulator starts at -(alpha s + g), P3 adds beta u
               const float a2 = e2 * zi;
-              float ge = gcur[j];
-              if (in_diag && ok && region >= p.strip) ge += dmap[(size_t)(word - dw0) * sout + region];
               O::from_f32(img + word * IMP + region * ESZ, be * a2);
               a1r[j][q] = a1;
-              acc[j][q] = -al * acc[j][q] - (ok ? ge : 0.f);
-              zacc += a2 * ge;                   // kappa gains sum_r a2 g  (softmax-over-regions backward)
+              if (AUX) {
+                float ge = gcur[j];
+                if (in_diag && ok && region >= p.strip) ge += dmap[(size_t)(word - dw0) * sout + region];
+                acc[j][q] = -al * acc[j][q] - (ok ? ge : 0.f);
+                zacc += a2 * ge;                 // kappa gains sum_r a2 g  (softmax-over-regions backward)
+              } else {
+                acc[j][q] = -al * acc[j][q];
+              }
             } else {
               O::from_f32(img + word * IMP + region * ESZ, e2);
               const float e2r = ESZ == 4 ? e2 : bf2f(f2bf(e2));        // as the MFMA will see it
@@ -601,7 +608,7 @@ __global__ void __launch_bounds__(NTHR) k_local_attn(LaParams p) {
           red[(1 * 8 + rslot) * TW + word] = d;
         }
       }
-    } else if (p.damean != nullptr || p.dattn != nullptr) {
+    } else if (AUX && (p.damean != nullptr || p.dattn != nullptr)) {
       const int rslot = wg * 2 + ((lane >> 4) & 1);
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
@@ -613,7 +620,7 @@ __global__ void __launch_bounds__(NTHR) k_local_attn(LaParams p) {
       }
     }
     __syncthreads();        // image complete (and the score tile is dead: the ring may be reused)
-    if (BWD && (p.damean != nullptr || p.dattn != nullptr) && tid < TW) {
+    if (BWD && AUX && (p.damean != nullptr || p.dattn != nullptr) && tid < TW) {
       float kg = 0.f;
 #pragma unroll
       for (int k = 0; k < 8; ++k) kg += red[(8 + k) * TW + tid];
@@ -1221,10 +1228,17 @@ int launch(LaParams& p, int op_dtype, void* stream) {
   hipStream_t st = (hipStream_t)stream;
 #define GLR_LAUNCH_K1(OP, FULL)                                                                                      \
   do {                                                                                                               \
-    if (hipFuncSetAttribute((const void*)k_local_attn<OP, BWD, FULL>, hipFuncAttributeMaxDynamicSharedMemorySize,   \
-                            lds) != hipSuccess)                                                                      \
-      return GLR_ELAUNCH;                                                                                            \
-    hipLaunchKernelGGL((k_local_attn<OP, BWD, FULL>), dim3(grid), dim3(NTHR), lds, st, p);                            \
+    if (BWD && (p.damean != nullptr || p.dattn != nullptr)) {                                                        \
+      if (hipFuncSetAttribute((const void*)k_local_attn<OP, BWD, FULL, BWD>,                                         \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)                        \
+        return GLR_ELAUNCH;                                                                                          \
+      hipLaunchKernelGGL((k_local_attn<OP, BWD, FULL, BWD>), dim3(grid), dim3(NTHR), lds, st, p);                     \
+    } else {                                                                                                         \
+      if (hipFuncSetAttribute((const void*)k_local_attn<OP, BWD, FULL, false>,                                       \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)                        \
+        return GLR_ELAUNCH;                                                                                          \
+      hipLaunchKernelGGL((k_local_attn<OP, BWD, FULL, false>), dim3(grid), dim3(NTHR), lds, st, p);                   \
+    }                                                                                                                \
   } while (0)
   const bool full = p.S_pad == GLR_MAX_SPAD;
   if (op_dtype == GLR_BF16) {
