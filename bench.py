@@ -173,10 +173,10 @@ def main():
             "roofline": {"bound": "mfma", "kernel": "k_local_attn_fwd (K1)", "achieved": achieved, "peak": peak,
                          "unit": "TFLOP/s", "frac": achieved / peak if peak else None,
                          # L2-side fabric bytes per launch from rocprofv3 PMC passes of this kernel at this shape
-                         # (FETCH_SIZE 970,922 KB x2 gfx950 read correction + WRITE_SIZE 424 KB;
-                         # profiles/r01_k1_pair_pmc_counters_v5.txt).  Infinity-Cache hits are counted: the 235 MB of
+                         # (FETCH_SIZE 977,733 KB x2 gfx950 read correction + WRITE_SIZE 23,976 KB;
+                         # profiles/r01_k1_pair_pmc_counters_v6.txt).  Infinity-Cache hits are counted: the 235 MB of
                          # operands fit the 256 MiB cache, the excess is word tiles re-read per image group
-                         "traffic": 1.94e9 if (world == 1 and args.precision == "bf16" and args.lengths == "mix") else None,
+                         "traffic": 1.98e9 if (world == 1 and args.precision == "bf16" and args.lengths == "mix") else None,
                          "launch_ms": k1_mean_s * 1e3, "launches": len(k1_ms)},
         }
         if world == 1 and not args.no_cpu_baseline:
