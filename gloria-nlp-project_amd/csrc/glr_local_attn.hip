@@ -84,6 +84,7 @@ struct LaParams {
   int strip;
   int pair_only, img_offset;
   int img_block;                // pair kernel: images per L2 group (block -> (image, item) mapping)
+  int t4;                       // experimental 4-wave kernel active (GLR_K1_T4=1)
   // backward only
   const float* dsim;            // [B_img][ld_sim]
   unsigned char* xout;          // [n_slots][B_img][S_pad] op dtype
@@ -846,6 +847,7 @@ __global__ void __launch_bounds__(NTHR) k_local_attn(LaParams p) {
 //       small           segment tables, reductions
 // A pair holds at most PAIR_MAXSEG sentences in total (planner: glr_plan_items).
 constexpr int PAIR_MAXSEG = 16;
+constexpr int T4_MAXSEG_FWD = 8;   // (see k_local_attn_t4)
 
 template <typename O>
 __global__ void __launch_bounds__(NTHR) k_local_attn_pair(LaParams p) {
@@ -905,6 +907,9 @@ __global__ void __launch_bounds__(NTHR) k_local_attn_pair(LaParams p) {
   // a pair is either two ordinary tiles or ONE sentence of 65..128 words that owns both tiles (the planner lists
   // it once per tile): a single segment spanning tile A and B
   const bool long_pair = p.tile_nsub[tile0] == 2;
+  if (p.t4 && !long_pair && p.tile_first[tile0 + 1] - p.tile_first[tile0] <= T4_MAXSEG_FWD &&
+      p.tile_first[tile0 + 2] - p.tile_first[tile0 + 1] <= T4_MAXSEG_FWD)
+    return;                                      // experimental: the 4-wave kernel runs this pair's tiles
   {
     const int sf0 = p.tile_first[tile0], sf2 = p.tile_first[tile0 + 2];
     const int ns = long_pair ? 1 : sf2 - sf0;
@@ -1190,6 +1195,362 @@ __global__ void __launch_bounds__(NTHR) k_local_attn_pair(LaParams p) {
 #undef GLR_SGQ
 }
 
+// ------------------------------------------------------------------------------------------
+// EXPERIMENTAL forward (GLR_K1_T4=1): one 64-word tile per 256-thread workgroup, TWO workgroups per CU.
+// Wave w owns region blocks {w, w+4, w+8} for BOTH 32-word blocks of the tile (2 x 48 accumulator registers), so
+// every vt / gram row is consumed by exactly one wave: the MFMA fragments of the region operand are loaded
+// straight from L2 into registers (global_load_dwordx4 from the K-tiled operands, three chunks ahead), no LDS
+// ring and no per-chunk barrier; the second workgroup of the CU runs its softmax phases meanwhile.
+// LDS (~77 KiB): [0, 60 KiB) statistics tables, later the e2 image (49 KiB) | lse table 12 KiB | small.
+// Handles ordinary tiles with at most T4_MAXSEG sentences (the pair kernel keeps the rest).
+constexpr int T4_MAXSEG = 8;
+constexpr int T4_NT = 256;
+constexpr int T4_PF = 3;                          // chunks of fragments in flight
+
+struct T4Frags { bf16x8 a0[2], a1[2], b[2][3]; };
+
+__global__ void __launch_bounds__(T4_NT) k_local_attn_t4(LaParams p) {
+  typedef OpBF16 O;
+  constexpr int ESZ = 2;
+  constexpr int SP = GLR_MAX_SPAD;
+  constexpr int IMP = SP * ESZ + 16;
+  constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);        // 0..3
+  const int l31 = lane & 31, h = lane >> 5;
+
+  // block -> (image, pair item, tile of the pair), image groups per XCD as in the pair kernel.
+  // (A persistent variant - 512 workgroups walking the units, the second layer started half a tile late to break the
+  //  lockstep of the two co-resident workgroups - measured 5 % slower than this one-unit-per-workgroup form.)
+  const int xcd = blockIdx.x & 7, qq = blockIdx.x >> 3;
+  const int ib = p.img_block;
+  const int per_grp = ib * p.n_items * 2;
+  const int grp = qq / per_grp, rem = qq - grp * per_grp;
+  const int b = (grp * ib + rem % ib) * 8 + xcd;
+  if (b >= p.B_img) return;
+  const int it = rem / ib;
+  const int tile0 = p.item_tile[it >> 1];
+  if (p.tile_nsub[tile0] != 0) return;                            // a long sentence owns this pair: pair kernel
+  const int tile = tile0 + (it & 1);
+  const int sf = p.tile_first[tile], NS = p.tile_first[tile + 1] - sf;
+  if (p.tile_first[tile0 + 1] - p.tile_first[tile0] > T4_MAXSEG || p.tile_first[tile0 + 2] - p.tile_first[tile0 + 1] > T4_MAXSEG)
+    return;                                                        // pair kernel takes the whole pair
+  const int D = p.D;
+
+  unsigned char* img = smem;
+  float* ps = reinterpret_cast<float*>(smem);                    // [4][T4_MAXSEG][SP]
+  float* mx = ps + 4 * T4_MAXSEG * SP;                           // [T4_MAXSEG][SP]
+  float* tab = mx + T4_MAXSEG * SP;                              // [T4_MAXSEG][SP]   lse, log2 units (survives P2)
+  signed char* wsegb = reinterpret_cast<signed char*>(tab + T4_MAXSEG * SP);   // [TW]
+  int* seg_w0 = reinterpret_cast<int*>(wsegb + TW);
+  int* seg_n = seg_w0 + T4_MAXSEG;
+  int* seg_sent = seg_n + T4_MAXSEG;
+  int* misc = seg_sent + T4_MAXSEG;                              // [1..2] diagonal w0, n
+  float* tnl = reinterpret_cast<float*>(misc + 8);               // [TW]
+  float* zsum = tnl + TW;
+  float* dsum = zsum + TW;
+  float* red = dsum + TW;                                        // [2][8][TW]
+
+  const size_t rowbytes1 = (size_t)D * ESZ, rowbytes2 = (size_t)SP * ESZ;
+  const unsigned char* vt_b = p.vt + (size_t)b * SP * rowbytes1;
+  const unsigned char* gram_b = p.gram + (size_t)b * SP * rowbytes2;
+  const unsigned char* tp_t = p.tp + (size_t)tile * TW * rowbytes1;
+
+  if (tid < TW) { wsegb[tid] = -1; tnl[tid] = p.tnorm[(size_t)tile * TW + tid]; }
+  if (tid < 3) misc[tid] = 0;
+  if (tid < NS) {
+    const int sent = p.order[sf + tid];
+    seg_sent[tid] = sent;
+    seg_w0[tid] = p.sent_slot0[sent] - tile * TW;
+    seg_n[tid] = p.cap_lens[sent];
+  }
+  __syncthreads();
+  if (tid < NS) {
+    const int w0 = seg_w0[tid], n = seg_n[tid];
+    for (int k = 0; k < n; ++k) wsegb[w0 + k] = (signed char)tid;
+    if (seg_sent[tid] == p.img_offset + b) { misc[1] = w0; misc[2] = n; }
+  }
+
+  // ================= P1: scores of both word blocks, operands straight from L2 =================
+  f32x16 acc0[3], acc1[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) { acc0[j][q] = 0.f; acc1[j][q] = 0.f; }
+  {
+    // K-tiled operands: chunk c of a block of R rows starts at c * R * 64; row r at + r * 64; k-step kk, half h at + kk*32 + h*16
+    const unsigned char* a_base = tp_t + l31 * CHB + h * 16;
+    const unsigned char* b_base = vt_b + (size_t)(w * 32 + l31) * CHB + h * 16;
+    auto load = [&](int c, T4Frags& f) {
+      const unsigned char* ac = a_base + (size_t)c * (TW * CHB);
+      const unsigned char* bc = b_base + (size_t)c * (SP * CHB);
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        f.a0[kk] = O::ld(ac + kk * 32);
+        f.a1[kk] = O::ld(ac + 32 * CHB + kk * 32);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) f.b[kk][j] = O::ld(bc + (size_t)j * (128 * CHB) + kk * 32);
+      }
+    };
+    auto mma = [&](const T4Frags& f) {
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          O::mma(f.a0[kk], f.b[kk][j], acc0[j]);
+          O::mma(f.a1[kk], f.b[kk][j], acc1[j]);
+        }
+    };
+    // D == 768 (checked at launch): 24 chunks, fully unrolled so that hipcc's waitcnt pass counts the loads in flight
+    // exactly (across a loop back-edge it falls back to vmcnt(0), which drains the three-chunk prefetch every trip)
+    constexpr int nch = 768 * ESZ / CHB;
+    T4Frags f0, f1, f2;
+    load(0, f0); load(1, f1); load(2, f2);
+    // the fences pin "MFMAs of chunk c, then the loads of chunk c+3": without them hipcc sinks every load next to
+    // its use and the prefetch distance collapses to a few instructions
+#define GLR_T4_STAGE(F, CC)                         \
+    __builtin_amdgcn_sched_barrier(0);              \
+    mma(F);                                         \
+    __builtin_amdgcn_sched_barrier(0);              \
+    if ((CC) < nch) load((CC), F);                  \
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int c = 0; c < nch; c += 3) {
+      GLR_T4_STAGE(f0, c + 3)
+      GLR_T4_STAGE(f1, c + 4)
+      GLR_T4_STAGE(f2, c + 5)
+    }
+#undef GLR_T4_STAGE
+  }
+
+  // ================= word-softmax statistics (as in the pair kernel; word block = t) =================
+  __syncthreads();
+  for (int i = tid; i < NS * SP; i += T4_NT) {
+    mx[i] = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) ps[k * T4_MAXSEG * SP + i] = 0.f;
+  }
+  int sg0[4], sg1[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    sg0[g] = *reinterpret_cast<const int*>(wsegb + 4 * h + 8 * g);
+    sg1[g] = *reinterpret_cast<const int*>(wsegb + 32 + 4 * h + 8 * g);
+  }
+#define GLR_SGQ(pk, q) (((pk)[(q) >> 2] << (24 - 8 * ((q) & 3))) >> 24)
+  __syncthreads();
+  const int rbase = w * 32 + l31;
+  auto run_max = [&](f32x16 (&acc)[3], const int (&pk)[4]) {
+    float rm[3] = {-INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int sg = GLR_SGQ(pk, q);
+      const bool last = (q == 15) || (GLR_SGQ(pk, (q + 1) & 15) != sg);
+#pragma unroll
+      for (int j = 0; j < 3; ++j) rm[j] = fmaxf(rm[j], acc[j][q]);
+      if (last && sg >= 0) {
+        float* dst = mx + sg * SP + rbase;
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+          __hip_atomic_fetch_max(dst + 128 * j, rm[j] * LOG2E, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+#pragma unroll
+      for (int j = 0; j < 3; ++j) rm[j] = last ? -INFINITY : rm[j];
+    }
+  };
+  run_max(acc0, sg0);
+  run_max(acc1, sg1);
+  __syncthreads();
+  auto run_sum = [&](f32x16 (&acc)[3], const int (&pk)[4], int t) {
+    float* psw = ps + (t * 2 + h) * T4_MAXSEG * SP;
+    float rs[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int sg = GLR_SGQ(pk, q);
+      const bool last = (q == 15) || (GLR_SGQ(pk, (q + 1) & 15) != sg);
+      const float* src = mx + max(sg, 0) * SP + rbase;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) rs[j] += __builtin_amdgcn_exp2f(__builtin_fmaf(acc[j][q], LOG2E, -src[128 * j]));
+      if (last && sg >= 0) {
+        float* dst = psw + sg * SP + rbase;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) dst[128 * j] = rs[j];
+      }
+#pragma unroll
+      for (int j = 0; j < 3; ++j) rs[j] = last ? 0.f : rs[j];
+    }
+  };
+  run_sum(acc0, sg0, 0);
+  run_sum(acc1, sg1, 1);
+  __syncthreads();
+  for (int i = tid; i < NS * SP; i += T4_NT) {
+    const int s2 = i / SP, r = i - s2 * SP;
+    const float sum = (ps[i] + ps[T4_MAXSEG * SP + i]) + (ps[2 * T4_MAXSEG * SP + i] + ps[3 * T4_MAXSEG * SP + i]);
+    const float l2 = mx[i] + __builtin_amdgcn_logf(sum);
+    tab[i] = l2;
+    if (p.lse) p.lse[((size_t)b * p.n_sent + seg_sent[s2]) * SP + r] = l2 * LN2;
+  }
+  __syncthreads();
+
+  // ================= P2: e2 image, per-word Z and dot~ =================
+  const float t1l = p.temp1 * LOG2E;
+  const int rslot = w * 2 + ((lane >> 4) & 1);
+  float okr[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) okr[j] = (rbase + 128 * j < p.S_eff) ? 1.f : 0.f;
+  auto p2 = [&](f32x16 (&acc)[3], const int (&pk)[4], int t) {
+    unsigned char* imgw = img + (t * 32 + 4 * h) * IMP + rbase * ESZ;
+    float* redt = red + rslot * TW + t * 32 + 4 * h;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int row = (q & 3) + 8 * (q >> 2);
+      const float* src = tab + max(GLR_SGQ(pk, q), 0) * SP + rbase;
+      float zacc = 0.f, dacc = 0.f;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const float a1 = __builtin_amdgcn_exp2f(__builtin_fmaf(acc[j][q], LOG2E, -src[128 * j]));
+        const float e2 = __builtin_amdgcn_exp2f(t1l * a1);
+        O::from_f32(imgw + row * IMP + 128 * j * ESZ, e2);
+        const float e2r = bf2f(f2bf(e2));
+        zacc = __builtin_fmaf(e2r, okr[j], zacc);
+        dacc = __builtin_fmaf(e2r, acc[j][q], dacc);
+        acc[j][q] = 0.f;
+      }
+      const float z = row_sum16(zacc), d = row_sum16(dacc);
+      if ((lane & 15) == 15) {
+        redt[row] = z;
+        redt[8 * TW + row] = d;
+      }
+    }
+  };
+  // the image aliases the ps tables: every wave must be past its table reads (tab lives above)
+  p2(acc0, sg0, 0);
+  p2(acc1, sg1, 1);
+  __syncthreads();
+  if (tid < TW) {
+    float z = 0.f, d = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { z += red[k * TW + tid]; d += red[(8 + k) * TW + tid]; }
+    zsum[tid] = z;
+    dsum[tid] = d;
+  }
+
+  // ================= P3: acc = image . G^T, Gram rows straight from L2 =================
+  {
+    const unsigned char* b_base = gram_b + (size_t)(w * 32 + l31) * CHB + h * 16;
+    const unsigned char* a_base = img + l31 * IMP + h * 16;
+    struct GF { bf16x8 b[2][3]; };
+    auto load = [&](int c, GF& f) {
+      const unsigned char* bc = b_base + (size_t)c * (SP * CHB);
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) f.b[kk][j] = O::ld(bc + (size_t)j * (128 * CHB) + kk * 32);
+    };
+    auto mma = [&](int c, const GF& f) {
+      bf16x8 a0[2], a1[2];
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        a0[kk] = O::ld(a_base + c * CHB + kk * 32);
+        a1[kk] = O::ld(a_base + 32 * IMP + c * CHB + kk * 32);
+      }
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          O::mma(a0[kk], f.b[kk][j], acc0[j]);
+          O::mma(a1[kk], f.b[kk][j], acc1[j]);
+        }
+    };
+    constexpr int nch = SP * ESZ / CHB;                            // 12
+    GF g0, g1, g2;
+    load(0, g0); load(1, g1); load(2, g2);
+#define GLR_T4_STAGE(C0, F, CC)                     \
+    __builtin_amdgcn_sched_barrier(0);              \
+    mma((C0), F);                                   \
+    __builtin_amdgcn_sched_barrier(0);              \
+    if ((CC) < nch) load((CC), F);                  \
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int c = 0; c < nch; c += 3) {
+      GLR_T4_STAGE(c, g0, c + 3)
+      GLR_T4_STAGE(c + 1, g1, c + 4)
+      GLR_T4_STAGE(c + 2, g2, c + 5)
+    }
+#undef GLR_T4_STAGE
+  }
+
+  // ================= P4 =================
+  auto p4 = [&](f32x16 (&acc)[3], int t) {
+    const unsigned char* imgw = img + (t * 32 + 4 * h) * IMP + rbase * ESZ;
+    float* redt = red + rslot * TW + t * 32 + 4 * h;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int row = (q & 3) + 8 * (q >> 2);
+      float v = 0.f;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) v += O::to_f32(imgw + row * IMP + 128 * j * ESZ) * acc[j][q];
+      v = row_sum16(v);
+      if ((lane & 15) == 15) redt[row] = v;
+    }
+  };
+  __syncthreads();                    // zsum / dsum done with red
+  p4(acc0, 0);
+  p4(acc1, 1);
+  __syncthreads();
+  if (tid < TW) {
+    float nn = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) nn += red[k * TW + tid];
+    const float z = zsum[tid], dd = dsum[tid];
+    float cosv = 0.f, nc2 = 0.f;
+    if (z > 0.f) {
+      const float iz = 1.f / z;
+      nc2 = fmaxf(nn, 0.f) * iz * iz;
+      const float den = fmaxf(tnl[tid] * sqrtf(nc2), p.eps);
+      cosv = dd * iz / den;
+    }
+    if (p.wstat) {
+      float* ws = p.wstat + ((size_t)b * p.n_slots + (size_t)tile * TW + tid) * WSTAT;
+      ws[0] = z; ws[1] = cosv; ws[2] = nc2; ws[3] = 0.f;
+    }
+    const int sg = wsegb[tid];
+    float v = __expf(p.temp2 * cosv);
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const float o = __shfl_up(v, off, 64);
+      const int so = __shfl_up(sg, off, 64);
+      if (lane >= off && so == sg) v = (p.agg == GLR_AGG_MAX) ? fmaxf(v, o) : v + o;
+    }
+    const int snext = __shfl_down(sg, 1, 64);
+    if (sg >= 0 && (lane == 63 || snext != sg)) {
+      if (p.agg == GLR_AGG_MEAN) v /= (float)seg_n[sg];
+      p.sim[(size_t)b * p.ld_sim + seg_sent[sg]] = p.temp3 * __logf(v);
+    }
+  }
+  const int dw0 = misc[1], dn = misc[2];
+  if (p.attn != nullptr && dn > 0) {
+    const int sout = p.S_eff - p.strip;
+    float* out = p.attn + p.attn_off[p.img_offset + b];
+    for (int idx = tid; idx < dn * sout; idx += T4_NT) {
+      const int wq = idx / sout, r = idx % sout + p.strip;
+      out[idx] = O::to_f32(img + (dw0 + wq) * IMP + r * ESZ) / zsum[dw0 + wq];
+    }
+  }
+  if (p.amean != nullptr) {
+    for (int r = tid; r < SP; r += T4_NT)
+      for (int s2 = 0; s2 < NS; ++s2) {
+        const int w0 = seg_w0[s2], n = seg_n[s2];
+        float a = 0.f;
+        for (int k = 0; k < n; ++k) a += O::to_f32(img + (w0 + k) * IMP + r * ESZ) / zsum[w0 + k];
+        p.amean[((size_t)b * p.n_sent + seg_sent[s2]) * SP + r] = r < p.S_eff ? a / (float)n : 0.f;
+      }
+  }
+#undef GLR_SGQ
+}
+
 #ifdef GLR_STAMPS
 unsigned long long* g_stamps = nullptr;
 unsigned long long* g_stamps2 = nullptr;
@@ -1261,9 +1622,18 @@ int launch_pair(LaParams& p, int op_dtype, void* stream) {
   p.img_block = env_ib > 0 ? env_ib : 4;
   const int per_xcd = ((p.B_img + 7) / 8 + p.img_block - 1) / p.img_block * p.img_block;
   const int grid = per_xcd * 8 * p.n_items;
+  static const bool env_t4 = [] { const char* e = getenv("GLR_K1_T4"); return e && atoi(e) == 1; }();
+  p.t4 = (env_t4 && p.D == 768) ? 1 : 0;
   if (hipFuncSetAttribute((const void*)k_local_attn_pair<OpBF16>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return GLR_ELAUNCH;
   hipLaunchKernelGGL((k_local_attn_pair<OpBF16>), dim3(grid), dim3(NTHR), lds, (hipStream_t)stream, p);
   GLR_CHECK_LAUNCH();
+  if (env_t4 && p.D == 768) {
+    // [0, 60 KiB) tables / image | lse table | small
+    const int lds4 = (4 + 1 + 1) * T4_MAXSEG * GLR_MAX_SPAD * 4 + 6144;
+    if (hipFuncSetAttribute((const void*)k_local_attn_t4, hipFuncAttributeMaxDynamicSharedMemorySize, lds4) != hipSuccess) return GLR_ELAUNCH;
+    hipLaunchKernelGGL(k_local_attn_t4, dim3(2 * grid), dim3(T4_NT), lds4, (hipStream_t)stream, p);
+    GLR_CHECK_LAUNCH();
+  }
   return GLR_OK;
 }
 
@@ -1279,7 +1649,7 @@ int fill_common(LaParams& p, const void* vt, const void* gram, const void* tp, c
   if (agg < 0 || agg > 2) return GLR_EINVAL;
   p.vt = (const unsigned char*)vt; p.gram = (const unsigned char*)gram; p.tp = (const unsigned char*)tp;
   p.tnorm = tnorm; p.sent_slot0 = sent_slot0; p.cap_lens = cap_lens; p.tile_first = tile_first; p.order = order;
-  p.tile_nsub = tile_nsub; p.item_tile = nullptr; p.n_items = 0; p.amean = nullptr; p.damean = nullptr; p.dattn = nullptr; p.n_tiles = n_tiles; p.n_sent = n_sent;
+  p.tile_nsub = tile_nsub; p.item_tile = nullptr; p.n_items = 0; p.amean = nullptr; p.damean = nullptr; p.dattn = nullptr; p.t4 = 0; p.n_tiles = n_tiles; p.n_sent = n_sent;
   p.n_slots = n_tiles * TW; p.B_img = B_img;
   p.D = D; p.S_eff = S_eff; p.S_pad = S_pad; p.temp1 = temp1; p.temp2 = temp2; p.temp3 = temp3; p.agg = agg;
   p.eps = eps;
