@@ -37,6 +37,7 @@
 //
 // Wave w: wm = w & 1 -> 32-word block; wg = w >> 1 -> region blocks {wg, wg+4, wg+8}.
 // Accumulator element q of a block: word row (q&3) + 8*(q>>2) + 4*(lane>>5), region column lane&31.
+#include <cstdio>
 #include <cstdlib>
 
 #include "glr_common.h"
@@ -85,6 +86,7 @@ struct LaParams {
   int pair_only, img_offset;
   int img_block;                // pair kernel: images per L2 group (block -> (image, item) mapping)
   int t4;                       // experimental 4-wave kernel active (GLR_K1_T4=1)
+  const unsigned char *vt_f, *gram_f, *tp_f;   // its fragment-major operands (glr_tile_frag)
   // backward only
   const float* dsim;            // [B_img][ld_sim]
   unsigned char* xout;          // [n_slots][B_img][S_pad] op dtype
@@ -1255,9 +1257,9 @@ __global__ void __launch_bounds__(T4_NT) k_local_attn_t4(LaParams p) {
   float* red = dsum + TW;                                        // [2][8][TW]
 
   const size_t rowbytes1 = (size_t)D * ESZ, rowbytes2 = (size_t)SP * ESZ;
-  const unsigned char* vt_b = p.vt + (size_t)b * SP * rowbytes1;
-  const unsigned char* gram_b = p.gram + (size_t)b * SP * rowbytes2;
-  const unsigned char* tp_t = p.tp + (size_t)tile * TW * rowbytes1;
+  const unsigned char* vt_b = p.vt_f + (size_t)b * SP * rowbytes1;
+  const unsigned char* gram_b = p.gram_f + (size_t)b * SP * rowbytes2;
+  const unsigned char* tp_t = p.tp_f + (size_t)tile * TW * rowbytes1;
 
   if (tid < TW) { wsegb[tid] = -1; tnl[tid] = p.tnorm[(size_t)tile * TW + tid]; }
   if (tid < 3) misc[tid] = 0;
@@ -1281,18 +1283,19 @@ __global__ void __launch_bounds__(T4_NT) k_local_attn_t4(LaParams p) {
 #pragma unroll
     for (int q = 0; q < 16; ++q) { acc0[j][q] = 0.f; acc1[j][q] = 0.f; }
   {
-    // K-tiled operands: chunk c of a block of R rows starts at c * R * 64; row r at + r * 64; k-step kk, half h at + kk*32 + h*16
-    const unsigned char* a_base = tp_t + l31 * CHB + h * 16;
-    const unsigned char* b_base = vt_b + (size_t)(w * 32 + l31) * CHB + h * 16;
+    // fragment-major operands: fragment (chunk c, 32-row block rb, k-step kk) = 1 KiB at ((c * NRB + rb) * 2 + kk) * 1024,
+    // lane i at + 16 i
+    const unsigned char* a_base = tp_t + lane * 16;
+    const unsigned char* b_base = vt_b + (size_t)w * 2048 + lane * 16;
     auto load = [&](int c, T4Frags& f) {
-      const unsigned char* ac = a_base + (size_t)c * (TW * CHB);
-      const unsigned char* bc = b_base + (size_t)c * (SP * CHB);
+      const unsigned char* ac = a_base + (size_t)c * (TW * CHB);           // 2 row blocks x 2 k-steps per chunk = 4 KiB
+      const unsigned char* bc = b_base + (size_t)c * (SP * CHB);           // 12 row blocks per chunk = 24 KiB
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
-        f.a0[kk] = O::ld(ac + kk * 32);
-        f.a1[kk] = O::ld(ac + 32 * CHB + kk * 32);
+        f.a0[kk] = O::ld(ac + kk * 1024);
+        f.a1[kk] = O::ld(ac + 2048 + kk * 1024);
 #pragma unroll
-        for (int j = 0; j < 3; ++j) f.b[kk][j] = O::ld(bc + (size_t)j * (128 * CHB) + kk * 32);
+        for (int j = 0; j < 3; ++j) f.b[kk][j] = O::ld(bc + (size_t)j * (4 * 2048) + kk * 1024);
       }
     };
     auto mma = [&](const T4Frags& f) {
@@ -1439,7 +1442,7 @@ __global__ void __launch_bounds__(T4_NT) k_local_attn_t4(LaParams p) {
 
   // ================= P3: acc = image . G^T, Gram rows straight from L2 =================
   {
-    const unsigned char* b_base = gram_b + (size_t)(w * 32 + l31) * CHB + h * 16;
+    const unsigned char* b_base = gram_b + (size_t)w * 2048 + lane * 16;
     const unsigned char* a_base = img + l31 * IMP + h * 16;
     struct GF { bf16x8 b[2][3]; };
     auto load = [&](int c, GF& f) {
@@ -1447,7 +1450,7 @@ __global__ void __launch_bounds__(T4_NT) k_local_attn_t4(LaParams p) {
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-        for (int j = 0; j < 3; ++j) f.b[kk][j] = O::ld(bc + (size_t)j * (128 * CHB) + kk * 32);
+        for (int j = 0; j < 3; ++j) f.b[kk][j] = O::ld(bc + (size_t)j * (4 * 2048) + kk * 1024);
     };
     auto mma = [&](int c, const GF& f) {
       bf16x8 a0[2], a1[2];
@@ -1551,6 +1554,8 @@ __global__ void __launch_bounds__(T4_NT) k_local_attn_t4(LaParams p) {
 #undef GLR_SGQ
 }
 
+const unsigned char *g_t4_vt = nullptr, *g_t4_gram = nullptr, *g_t4_tp = nullptr;   // fragment-major operands (experimental)
+
 #ifdef GLR_STAMPS
 unsigned long long* g_stamps = nullptr;
 unsigned long long* g_stamps2 = nullptr;
@@ -1623,13 +1628,24 @@ int launch_pair(LaParams& p, int op_dtype, void* stream) {
   const int per_xcd = ((p.B_img + 7) / 8 + p.img_block - 1) / p.img_block * p.img_block;
   const int grid = per_xcd * 8 * p.n_items;
   static const bool env_t4 = [] { const char* e = getenv("GLR_K1_T4"); return e && atoi(e) == 1; }();
-  p.t4 = (env_t4 && p.D == 768) ? 1 : 0;
+  const bool use_t4 = env_t4 && p.D == 768 && g_t4_vt && g_t4_gram && g_t4_tp;
+  p.t4 = use_t4 ? 1 : 0;
+  p.vt_f = g_t4_vt; p.gram_f = g_t4_gram; p.tp_f = g_t4_tp;
   if (hipFuncSetAttribute((const void*)k_local_attn_pair<OpBF16>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return GLR_ELAUNCH;
   hipLaunchKernelGGL((k_local_attn_pair<OpBF16>), dim3(grid), dim3(NTHR), lds, (hipStream_t)stream, p);
   GLR_CHECK_LAUNCH();
-  if (env_t4 && p.D == 768) {
+  if (use_t4) {
     // [0, 60 KiB) tables / image | lse table | small
-    const int lds4 = (4 + 1 + 1) * T4_MAXSEG * GLR_MAX_SPAD * 4 + 6144;
+    // GLR_K1_T4_PAD (diagnostic): extra LDS bytes, e.g. 8192 forces ONE workgroup per CU
+    static const int env_pad = [] { const char* e = getenv("GLR_K1_T4_PAD"); return e ? atoi(e) : 0; }();
+    const int lds4 = (4 + 1 + 1) * T4_MAXSEG * GLR_MAX_SPAD * 4 + 6144 + env_pad;
+    static bool said = false;
+    if (!said && getenv("GLR_K1_T4_VERBOSE")) {
+      int nb = 0;
+      (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)k_local_attn_t4, T4_NT, lds4);
+      fprintf(stderr, "[glr] k_local_attn_t4: %d bytes of LDS, %d workgroups per CU\n", lds4, nb);
+      said = true;
+    }
     if (hipFuncSetAttribute((const void*)k_local_attn_t4, hipFuncAttributeMaxDynamicSharedMemorySize, lds4) != hipSuccess) return GLR_ELAUNCH;
     hipLaunchKernelGGL(k_local_attn_t4, dim3(2 * grid), dim3(T4_NT), lds4, (hipStream_t)stream, p);
     GLR_CHECK_LAUNCH();
@@ -1665,6 +1681,11 @@ int fill_common(LaParams& p, const void* vt, const void* gram, const void* tp, c
 }
 
 }  // namespace
+
+extern "C" int glr_set_t4_operands(const void* vt_f, const void* gram_f, const void* tp_f) {
+  g_t4_vt = (const unsigned char*)vt_f; g_t4_gram = (const unsigned char*)gram_f; g_t4_tp = (const unsigned char*)tp_f;
+  return GLR_OK;
+}
 
 extern "C" int glr_local_attn_fwd(const void* vt, const void* gram, const void* tp, const float* tnorm,
                                   const int32_t* sent_slot0, const int32_t* cap_lens,

@@ -180,7 +180,34 @@ __global__ void k_tile_k(const uint4* __restrict__ src, uint4* __restrict__ dst,
   dst[i] = src[((blk * rows + r) * nch + c) * 4 + s16];
 }
 
+// Fragment-major packing (experimental k_local_attn_t4): every MFMA operand fragment - 32 rows x 32 bytes of K, i.e.
+// the 16 bytes each of the 64 lanes feeds to one v_mfma_f32_32x32x16_bf16 - is stored as 1 KiB contiguous in lane
+// order: [block][K chunk of 64 B][32-row block][k-step of the chunk][lane][16 B].
+__global__ void k_tile_frag(const uint4* __restrict__ src, uint4* __restrict__ dst, int rows, int nch, size_t total) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int lane = (int)(i & 63);
+  size_t f = i >> 6;
+  const int kk = (int)(f & 1); f >>= 1;
+  const int nrb = rows / 32;
+  const int rb = (int)(f % nrb); f /= nrb;
+  const int c = (int)(f % nch);
+  const size_t blk = f / nch;
+  const int row = rb * 32 + (lane & 31);
+  const int piece = c * 4 + kk * 2 + (lane >> 5);              // 16-byte piece inside the row
+  dst[i] = src[(blk * rows + row) * (size_t)(nch * 4) + piece];
+}
+
 }  // namespace
+
+extern "C" int glr_tile_frag(const void* src, void* dst, int rows, long long n_blocks, int row_bytes, void* stream) {
+  if (!src || !dst || rows <= 0 || rows % 32 != 0 || n_blocks <= 0 || row_bytes <= 0 || row_bytes % 64 != 0) return GLR_EINVAL;
+  const size_t total = (size_t)n_blocks * rows * (row_bytes / 16);
+  hipLaunchKernelGGL(k_tile_frag, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const uint4*)src, (uint4*)dst, rows, row_bytes / 64, total);
+  GLR_CHECK_LAUNCH();
+  return GLR_OK;
+}
 
 extern "C" int glr_tile_k(const void* src, void* dst, int rows, long long n_blocks, int row_bytes, void* stream) {
   if (!src || !dst || rows <= 0 || n_blocks <= 0 || row_bytes <= 0 || row_bytes % 64 != 0) return GLR_EINVAL;

@@ -28,6 +28,8 @@ SYMBOLS = {
     "glr_plan_tiles": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "glr_plan_items": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "glr_tile_k": (c_int, [c_void_p, c_void_p, c_int, ctypes.c_longlong, c_int, c_void_p]),
+    "glr_tile_frag": (c_int, [c_void_p, c_void_p, c_int, ctypes.c_longlong, c_int, c_void_p]),
+    "glr_set_t4_operands": (c_int, [c_void_p, c_void_p, c_void_p]),
     "glr_pack_regions": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "glr_pack_words": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                c_int, c_int, c_int, c_void_p]),

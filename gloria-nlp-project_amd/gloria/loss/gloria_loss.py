@@ -23,6 +23,9 @@ import torch
 from .. import _native as N
 from . import _recompute as R
 
+import os
+
+_T4 = os.environ.get("GLR_K1_T4", "0") == "1"      # experimental K1 forward kernel
 _COMPUTE_DTYPE = None          # None = follow the input dtype
 K1_EVENTS = None               # bench.py sets this to a list to collect (start, end, flops) of every K1 launch
 
@@ -104,6 +107,16 @@ def _pack_operands(img_features, words, no_attn_vec, cap_lens, o):
     N.check(L.glr_tile_k(N.ptr(vt), N.ptr(vt_t), s_pad, B, D * esz, st), "glr_tile_k")
     N.check(L.glr_tile_k(N.ptr(gram), N.ptr(gram_t), s_pad, B, s_pad * esz, st), "glr_tile_k")
     N.check(L.glr_tile_k(N.ptr(tp), N.ptr(tp_t), N.TILE_WORDS, plan.n_tiles, D * esz, st), "glr_tile_k")
+    if _T4 and code == N.GLR_BF16 and s_pad == N.MAX_SPAD and D == 768:
+        # experimental forward kernel (GLR_K1_T4=1): fragment-major copies of the three operands
+        keep = [torch.empty_like(vt), torch.empty_like(gram), torch.empty_like(tp)]
+        N.check(L.glr_tile_frag(N.ptr(vt), N.ptr(keep[0]), s_pad, B, D * esz, st), "glr_tile_frag")
+        N.check(L.glr_tile_frag(N.ptr(gram), N.ptr(keep[1]), s_pad, B, s_pad * esz, st), "glr_tile_frag")
+        N.check(L.glr_tile_frag(N.ptr(tp), N.ptr(keep[2]), N.TILE_WORDS, plan.n_tiles, D * esz, st), "glr_tile_frag")
+        L.glr_set_t4_operands(N.ptr(keep[0]), N.ptr(keep[1]), N.ptr(keep[2]))
+        plan._t4_keep = keep                     # alive until the forward launch has been queued (same stream)
+    elif _T4:
+        L.glr_set_t4_operands(None, None, None)
     return plan, code, vt, vt_t, gram_t, tp, tp_t, tnorm, s_eff, s_pad, shift
 
 

@@ -181,6 +181,11 @@ int glr_local_attn_bwd(const void* vt, const void* gram, const void* tp, const f
  *   src   row-major [n_blocks * rows][row_bytes]     dst  same size, tiled     row_bytes % 64 == 0
  */
 int glr_tile_k(const void* src, void* dst, int rows, long long n_blocks, int row_bytes, void* stream);
+/* Fragment-major packing for the experimental forward kernel (GLR_K1_T4=1): every 32-row x 32-byte MFMA operand
+ * fragment 1 KiB contiguous in lane order; rows % 32 == 0.  glr_set_t4_operands hands the three packed operands
+ * (vt, gram, tp; NULL to clear) to the next glr_local_attn_fwd calls of this process. */
+int glr_tile_frag(const void* src, void* dst, int rows, long long n_blocks, int row_bytes, void* stream);
+int glr_set_t4_operands(const void* vt_f, const void* gram_f, const void* tp_f);
 
 /* ------------------------------------------------------------------------------------------
  * K2  dual cross-entropy on a square similarity matrix (labels = arange).
