@@ -3,7 +3,7 @@
 //   mode 1: registers (global_load_dwordx4 -> ds_write_b128)
 //   mode 2: registers only (global_load_dwordx4, no LDS write; values xor-folded)
 // Every workgroup streams the same per-XCD-shared buffer of `bytes` (vt[b]-like, 590 KB) `reps` times.
-// Build: hipcc -O3 --offload-arch=gfx950 -o l2_to_lds l2_to_lds.hip
+// Build: hipcc -O3 --offload-arch=gfx950 -o l2_to_lds l2_to_lds.hip   (the binary is not kept in the repository)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
