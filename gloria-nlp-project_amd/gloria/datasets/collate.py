@@ -1,0 +1,221 @@
+"""GloriaCollateFn with the reference's interface (/root/reference/gloria/datasets/mimic_for_gloria.py:58-263),
+image half on the GPU.
+
+  process_img(images, device)   :120-133  list of 2-D images -> float32 [B, 3, crop, crop] in [-1, 1].  The reference
+        loops over images on the host (cv2.INTER_AREA resize, np.pad, PIL "L"->"RGB", RandomCrop/CenterCrop, ToTensor,
+        Normalize) and uploads the result; here the raw images are uploaded once (one packed buffer) and
+        glr_image_minmax + glr_collate_images (csrc/glr_collate.hip) produce the batch tensor directly.
+        Raw (non-uint8) images take the min-max -> uint8 conversion of original_tensor_to_numpy_image (:36-42) on
+        the GPU as well (`__call__` hands them over unconverted).
+  _resize_plan                  :136-181  the size / padding arithmetic of `_resize_img` (host integers)
+  process_text(text, device)    :184-263  report cleaning + tokenisation; nltk's RegexpTokenizer(r"\\w+") is the
+        regular expression itself, the tokenizer is a local BERT vocabulary (no network: `bert_type` must be a
+        local directory / vocab file or a tokenizer object is passed in)
+  get_batch / __call__          :66-108   sort by caption length (descending), permute every field alike
+
+Not built: segmentation labels from bounding boxes (:110-118, `bboxes` raises), the random flip / affine / colour
+transforms of builder.py:167-186 (unused by configs/imagenome_pretrain_config.yaml), images smaller than `imsize`
+(cv2 would upscale with its bilinear branch).  There is no CPU path: process_img needs the HIP library and a GPU.
+"""
+
+import math
+import os
+import random
+import re
+
+import numpy as np
+import torch
+
+from .. import _native as N
+
+_SRC_CODE = {np.dtype(np.uint8): 0, np.dtype(np.int16): 1, np.dtype(np.float32): 2}
+_SPLITTER = re.compile(r"[0-9]+\.")
+_WORD = re.compile(r"\w+")
+
+
+def resize_plan(h, w, scale):
+    """(dst_h, dst_w, pad_top, pad_left) of `_resize_img` (mimic_for_gloria.py:143-176)."""
+    if h >= w:                                    # size.index(max(size)) == 0, also for square images
+        pct = scale / float(h)
+        dh, dw = scale, int(float(w) * float(pct))
+        return dh, dw, 0, int(math.floor((scale - dw) / 2))
+    pct = scale / float(w)
+    dh, dw = int(float(h) * float(pct)), scale
+    return dh, dw, int(math.floor((scale - dh) / 2)), 0
+
+
+def collate_images(images, crop_offsets, scale=256, crop=224, device="cuda", minmax=None):
+    """images: list of 2-D numpy arrays / torch tensors.  uint8 images are taken as they are (minmax=False) unless
+    minmax=True; other dtypes are min-max normalised to uint8 on the GPU.  Returns float32 [B, 3, crop, crop]."""
+    arrs = []
+    for im in images:
+        a = im.detach().cpu().numpy() if isinstance(im, torch.Tensor) else np.asarray(im)
+        if a.ndim != 2:
+            raise ValueError(f"expected single-channel 2-D images, got shape {a.shape}")
+        arrs.append(a)
+    if not arrs:
+        raise ValueError("empty image batch")
+    dt = arrs[0].dtype if all(a.dtype == arrs[0].dtype for a in arrs) else np.dtype(np.float32)
+    if dt not in _SRC_CODE:
+        dt = np.dtype(np.float32)                 # image.float() of the reference (:37)
+    if minmax is None:
+        minmax = dt != np.dtype(np.uint8)
+    if not minmax and dt != np.dtype(np.uint8):
+        raise ValueError("images that are not uint8 need the min-max conversion")
+    desc = np.zeros((len(arrs), 8), dtype=np.int32)
+    offsets = np.zeros(len(arrs), dtype=np.int64)
+    total = 0
+    for b, (a, (cy, cx)) in enumerate(zip(arrs, crop_offsets)):
+        h, w = a.shape
+        if max(h, w) < scale:
+            raise NotImplementedError(f"image {h}x{w} is smaller than imsize={scale}: cv2 would upscale (not built)")
+        dh, dw, top, left = resize_plan(h, w, scale)
+        if dh <= 0 or dw <= 0:
+            raise ValueError(f"degenerate image {h}x{w}")
+        if not (0 <= cy <= scale - crop and 0 <= cx <= scale - crop):
+            raise ValueError("crop window outside the frame")
+        desc[b] = (h, w, dh, dw, top, left, cy, cx)
+        offsets[b] = total
+        total += (h * w * dt.itemsize + 15) // 16 * 16
+    host = torch.empty(total, dtype=torch.uint8).pin_memory() if torch.cuda.is_available() else torch.empty(total, dtype=torch.uint8)
+    hv = host.numpy()
+    for a, o in zip(arrs, offsets):
+        n = a.size * dt.itemsize
+        hv[o:o + n] = np.ascontiguousarray(a, dtype=dt).reshape(-1).view(np.uint8)
+    src = host.to(device, non_blocking=True)
+    N.require_cuda(src)
+    meta = torch.from_numpy(np.concatenate([offsets.view(np.int32), desc.reshape(-1)])).to(device, non_blocking=True)
+    off_d, desc_d = meta[:2 * len(arrs)], meta[2 * len(arrs):]
+    out = torch.empty(len(arrs), 3, crop, crop, dtype=torch.float32, device=device)
+    L = N.lib()
+    code = _SRC_CODE[dt]
+    state = None
+    if minmax:
+        state = torch.empty(len(arrs), 2, dtype=torch.int32, device=device)
+        N.check(L.glr_image_minmax(N.ptr(src), N.ptr(off_d), N.ptr(desc_d), len(arrs), code, N.ptr(state), N.stream()),
+                "glr_image_minmax")
+    N.check(L.glr_collate_images(N.ptr(src), N.ptr(off_d), N.ptr(desc_d), N.ptr(state), len(arrs), code, crop,
+                                 N.ptr(out), N.stream()), "glr_collate_images")
+    return out
+
+
+def clean_report(text, full_report=True, rng=random):
+    """mimic_for_gloria.py:190-223: sentence split, \\w+ tokens, ascii-only, lower case."""
+    text = text.replace("\n", " ")
+    captions = [sent for point in _SPLITTER.split(text) for sent in point.split(".")]
+    all_sents = []
+    for t in captions:
+        t = t.replace("\ufffd\ufffd", " ")
+        tokens = _WORD.findall(t.lower())
+        if len(tokens) <= 1:
+            continue
+        kept = [w for w in (tok.encode("ascii", "ignore").decode("ascii") for tok in tokens) if len(w) > 0]
+        all_sents.append(" ".join(kept))
+    if full_report is True:
+        return " ".join(all_sents)
+    return all_sents[rng.randint(0, len(all_sents) - 1)]
+
+
+def load_tokenizer(bert_type):
+    """A BERT word-piece tokenizer from a LOCAL directory or vocab.txt (the reference downloads
+    `AutoTokenizer.from_pretrained(bert_type)`, mimic_for_gloria.py:61; there is no network here)."""
+    from transformers import BertTokenizerFast
+    if os.path.isdir(bert_type):
+        return BertTokenizerFast.from_pretrained(bert_type, local_files_only=True)
+    if os.path.isfile(bert_type):
+        with open(bert_type, encoding="utf-8") as f:
+            vocab = {line.rstrip("\n"): i for i, line in enumerate(f)}
+        try:
+            return BertTokenizerFast(vocab=vocab, do_lower_case=True)          # transformers >= 5
+        except TypeError:
+            return BertTokenizerFast(vocab_file=bert_type, do_lower_case=True)   # transformers 4.x
+    raise FileNotFoundError(f"tokenizer '{bert_type}' is not a local directory or vocab file (no network access)")
+
+
+class GloriaCollateFn:
+    def __init__(self, cfg, split, device="cuda", include_instances=True, tokenizer=None):
+        self.cfg = cfg
+        self.tokenizer = tokenizer if tokenizer is not None else load_tokenizer(cfg.model.text.bert_type)
+        self.split = split
+        self.device = device
+        self.ixtoword = {v: k for k, v in self.tokenizer.get_vocab().items()}
+        self.include_instances = include_instances
+        t = cfg.transforms
+        for name in ("random_horizontal_flip", "random_affine", "color_jitter"):
+            if t is not None and getattr(t, name) is not None:
+                raise NotImplementedError(f"transforms.{name} is not built (builder.py:167-186)")
+        if t is None or t.norm != "half":
+            raise NotImplementedError("only Normalize(0.5, 0.5) ('half') is built (builder.py:196-197)")
+        self.scale = cfg.data.image.imsize
+        self.crop = t.random_crop.crop_size if (t is not None and t.random_crop is not None) else self.scale
+
+    # ---- images
+    def crop_offsets(self, n):
+        """RandomCrop.get_params for the train split (torchvision 0.8.2: i then j from torch.randint per image,
+        nothing drawn when the sizes are equal); CenterCrop otherwise (builder.py:162-190)."""
+        room = self.scale - self.crop
+        if room == 0:
+            return [(0, 0)] * n
+        if self.split == "train":
+            return [(int(torch.randint(0, room + 1, size=(1,)).item()), int(torch.randint(0, room + 1, size=(1,)).item()))
+                    for _ in range(n)]
+        o = int(round(room / 2.0))
+        return [(o, o)] * n
+
+    def process_img(self, images, device, minmax=None):
+        return collate_images(images, self.crop_offsets(len(images)), self.scale, self.crop, device, minmax)
+
+    # ---- text
+    def process_text(self, text, device, objects=None):
+        if objects is not None:
+            raise NotImplementedError
+        ids, att, typ, sents = [], [], [], []
+        for t in text:
+            t = clean_report(t, self.cfg.data.text.full_report)
+            enc = self.tokenizer(t, return_tensors="pt", truncation=True, padding="max_length",
+                                 max_length=self.cfg.data.text.word_num)
+            ids.append(enc["input_ids"])
+            att.append(enc["attention_mask"])
+            typ.append(enc["token_type_ids"])
+            sents.append([self.ixtoword[ix] for ix in enc["input_ids"][0].tolist()])
+        out = {}
+        for key, parts in (("caption_ids", ids), ("attention_mask", att), ("token_type_ids", typ)):
+            stacked = torch.stack(parts)
+            out[key] = (stacked.squeeze(0) if len(text) == 1 else stacked.squeeze()).to(device)
+        out["cap_lens"] = [len([w for w in s if not w.startswith("[")]) + 1 for s in sents]
+        return out
+
+    # ---- batch
+    def get_batch(self, images, captions, instances=None, sort=True, bboxes=None, minmax=None):
+        if bboxes is not None:
+            raise NotImplementedError("segmentation labels from bounding boxes (mimic_for_gloria.py:110-118) are not built")
+        imgs = self.process_img(images, self.device, minmax)
+        cap = self.process_text(captions, self.device)
+        lens = torch.tensor(cap["cap_lens"])
+        if sort:
+            lens, order = torch.sort(lens, 0, True)
+        else:
+            order = torch.arange(len(lens))
+        lens, order = lens.to(self.device), order.to(self.device)
+        batch = {k: v[order] for k, v in cap.items() if k != "cap_lens"}
+        batch["cap_lens"] = lens
+        batch["imgs"] = imgs[order]
+        if instances is not None:
+            batch["instances"] = [instances[i] for i in order.tolist()]
+        return batch
+
+    def __call__(self, instances):
+        images, captions, bboxes = [], [], []
+        for instance in instances:
+            patient_id = next(iter(instance.keys()))
+            study_id = next(iter(instance[patient_id].keys()))
+            inst = instance[patient_id][study_id]
+            dicom_id = next(iter(inst["images"].keys()))
+            images.append(inst["images"][dicom_id])          # raw: the min-max -> uint8 step runs on the GPU
+            if "sentence" in inst.keys():
+                captions.append(inst["sentence"])
+                bboxes.append(inst["objects"][dicom_id]["sent_to_bboxes"][inst["sent_id"]]["coords_original"])
+            else:
+                captions.append(inst["report"])
+        return self.get_batch(images, captions, instances=instances if self.include_instances else None,
+                              bboxes=bboxes if len(bboxes) > 0 else None, minmax=True)

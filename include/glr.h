@@ -45,6 +45,10 @@ extern "C" {
 #define GLR_MAX_SPAD 384  /* max padded region count (multiple of 64)          */
 #define GLR_MAX_WORDS 512 /* longest sentence (words) the planner accepts          */
 
+#define GLR_SRC_U8 0      /* element types of the raw images handed to glr_collate_images */
+#define GLR_SRC_I16 1
+#define GLR_SRC_F32 2
+
 /* ABI version; bumped on any signature change. */
 int glr_version(void);
 
@@ -301,6 +305,30 @@ int glr_bn_act_fwd(const void* x, const void* residual, const float* gamma, cons
 int glr_bn_act_bwd(const void* x, const void* dy, const void* y, const float* gamma, const float* beta, const float* mean,
                    const float* invstd, long long R, int C, int relu, int has_residual, float* workspace, float* dgamma,
                    float* dbeta, float* tmp2c, void* dx, void* dres, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Image half of the collate function: replaces, for a ragged batch of single-channel images,
+ *   original_tensor_to_numpy_image   gloria/datasets/mimic_for_gloria.py:36-42  (min-max -> uint8, truncating)
+ *   GloriaCollateFn._resize_img      mimic_for_gloria.py:136-181   (cv2.INTER_AREA long side -> scale, zero pad)
+ *   GloriaCollateFn.process_img      mimic_for_gloria.py:120-133   ("L"->"RGB", crop, ToTensor, Normalize(0.5,0.5);
+ *                                    transform of gloria/builder.py:159-201 for configs/imagenome_pretrain_config.yaml)
+ * src     one device buffer holding the B images back to back (row-major H x W, element type src_dtype);
+ * offset  [B] device int64: byte offset of each image in src (16-byte aligned offsets use vector loads);
+ * desc    [B][8] device int32 per image: { H, W, dst_h, dst_w, pad_top, pad_left, crop_top, crop_left } where
+ *         dst_h x dst_w is the resized size (<= H x W: downscaling only), pad_* its position in the scale x scale
+ *         frame and crop_* the crop window's corner in that frame (host planning: gloria/datasets/collate.py);
+ * state   [B][2] device uint32: per-image min / max as order-preserving keys, written by glr_image_minmax and read
+ *         by glr_collate_images; NULL = src already holds the 8-bit image (src_dtype GLR_SRC_U8);
+ * out     float32 [B, 3, crop, crop] (crop <= 256), values in [-1, 1], three equal channels.
+ * One thread per output pixel evaluates OpenCV 4.5's INTER_AREA cell (integer-scale fast path incl. the 2x2 8-bit
+ * rounding, general fp32 tap path in OpenCV's summation order) from the source directly: no intermediate image is
+ * materialised and only pixels under the crop window are read.  Bit-exact against oracle/collate_oracle.py;
+ * HBM-bound (algorithmic bytes: H*W*esz read once for min-max, <= H*W*esz read + 12*crop^2 written by the collate).
+ */
+int glr_image_minmax(const void* src, const int64_t* offset, const int32_t* desc, int B, int src_dtype,
+                     uint32_t* state, void* stream);
+int glr_collate_images(const void* src, const int64_t* offset, const int32_t* desc, const uint32_t* state, int B,
+                       int src_dtype, int crop, float* out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,158 @@
+"""CPU tests of the collate function: the numpy restatement of the image path (oracle/collate_oracle.py,
+PARITY UNPINNED for the cv2.INTER_AREA stage: opencv-python==4.5.1.48 is absent and the reference holds no image
+fixtures) checked through known answers and an independent area average, plus the host-side text half."""
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import collate_oracle as co
+
+
+def test_resize_plan_matches_reference_arithmetic():
+    from gloria.datasets import collate
+    # mimic_for_gloria.py:143-176 by hand: 2544x3056 (wider): dst_h = int(2544 * 256/3056) = 213, pad 43 -> top 21
+    assert co.resize_plan(2544, 3056, 256) == (213, 256, 21, 0)
+    assert co.resize_plan(3056, 2544, 256) == (256, 213, 0, 21)
+    assert co.resize_plan(512, 512, 256) == (256, 256, 0, 0)          # square counts as "taller"
+    rng = np.random.default_rng(0)
+    for h, w in rng.integers(256, 4000, size=(200, 2)):
+        assert collate.resize_plan(int(h), int(w), 256) == co.resize_plan(int(h), int(w), 256)
+
+
+def test_min_max_to_uint8_truncates():
+    x = np.array([[0.0, 1.0], [2.0, 3.0]], dtype=np.float32)
+    assert co.to_u8(x).tolist() == [[0, 85], [170, 255]]                # 1/3*255 = 85.0, 2/3*255 = 170.0
+    x = np.array([[-5, 0, 7, 11]], dtype=np.int16)
+    want = [int(np.float32(np.float32(v + 5) / np.float32(16)) * np.float32(255)) for v in (-5, 0, 7, 11)]
+    assert co.to_u8(x).tolist() == [want]
+
+
+def test_area_fast_paths_known_answers():
+    src = np.array([[1, 2, 5, 5], [3, 4, 5, 6]], dtype=np.uint8)
+    assert co.resize_area_u8(src, 1, 2).tolist() == [[3, 5]]            # (10+2)>>2 = 3 (2.5 rounds UP), (21+2)>>2 = 5
+    src = np.arange(32, dtype=np.uint8).reshape(4, 8)
+    got = co.resize_area_u8(src, 1, 2)                                   # 4x4 boxes: means 13.5 / 17.5 -> half to even
+    assert got.tolist() == [[14, 18]]
+    src = np.full((6, 9), 10, dtype=np.uint8); src[0, 0] = 15            # 3x3 box sum 95 -> 95/9 = 10.56 -> 11
+    assert co.resize_area_u8(src, 2, 3).tolist() == [[11, 10, 10], [10, 10, 10]]
+    assert co.resize_area_u8(src, 6, 9) is not src and (co.resize_area_u8(src, 6, 9) == src).all()
+
+
+def test_area_tab_weights():
+    taps = co.area_tab(5, 2, 2.5)                                        # cells [0, 2.5) and [2.5, 5)
+    f = lambda v: float(np.float32(v))
+    assert [(s, float(a)) for s, a in taps[0]] == [(0, f(0.4)), (1, f(0.4)), (2, f(0.2))]
+    assert [(s, float(a)) for s, a in taps[1]] == [(2, f(0.2)), (3, f(0.4)), (4, f(0.4))]
+    for ssize, dsize in ((3056, 256), (2544, 213), (300, 256), (1033, 256)):
+        scale = 1.0 / (float(dsize) / ssize)
+        for t in co.area_tab(ssize, dsize, scale):
+            assert abs(sum(float(a) for _, a in t) - 1.0) < 1e-5
+            idx = [s for s, _ in t]
+            assert idx == list(range(idx[0], idx[0] + len(idx))) and 0 <= idx[0] and idx[-1] < ssize
+
+
+def exact_area_mean(src, dh, dw):
+    """independent float64 area average over the real-valued cells (no rounding order games)"""
+    sh, sw = src.shape
+
+    def weights(ssize, dsize):
+        m = np.zeros((dsize, ssize))
+        sc = ssize / dsize
+        for d in range(dsize):
+            lo, hi = d * sc, (d + 1) * sc
+            for s in range(int(np.floor(lo)), min(int(np.ceil(hi)), ssize)):
+                m[d, s] = max(0.0, min(hi, s + 1) - max(lo, s)) / sc
+        return m
+    return weights(sh, dh) @ src.astype(np.float64) @ weights(sw, dw).T
+
+
+@pytest.mark.parametrize("shape", [(300, 256), (777, 1033), (512, 501), (1000, 1024)])
+def test_general_area_path_is_an_area_average(shape):
+    rng = np.random.default_rng(sum(shape))
+    src = rng.integers(0, 256, size=shape, dtype=np.uint8)
+    dh, dw, _, _ = co.resize_plan(*shape, 256)
+    got = co.resize_area_u8(src, dh, dw).astype(np.float64)
+    want = exact_area_mean(src, dh, dw)
+    assert np.abs(got - want).max() <= 0.5 + 1e-3                        # correct rounding of the exact mean up to fp32 noise
+    const = np.full(shape, 201, dtype=np.uint8)
+    assert (co.resize_area_u8(const, dh, dw) == 201).all()
+
+
+def test_process_img_layout_and_range():
+    rng = np.random.default_rng(1)
+    imgs = [rng.integers(0, 256, size=s, dtype=np.uint8) for s in ((300, 400), (512, 512))]
+    out = co.process_img(imgs, [(3, 30), (16, 16)])
+    assert out.shape == (2, 3, 224, 224) and out.dtype == np.float32
+    assert (out[:, 0] == out[:, 1]).all() and (out[:, 0] == out[:, 2]).all()
+    assert out.min() >= -1 and out.max() <= 1
+    top = co.resize_plan(300, 400, 256)[2]                               # zero padding rows -> (0/255 - .5)/.5 = -1
+    assert (out[0, 0, : top - 3] == -1).all()
+    frame = co.resize_img(imgs[1], 256)
+    np.testing.assert_array_equal(out[1, 0], (frame[16:240, 16:240].astype(np.float32) / np.float32(255) - np.float32(0.5)) / np.float32(0.5))
+    with pytest.raises(ValueError):
+        co.resize_img(np.zeros((100, 200), dtype=np.uint8), 256)
+
+
+# ---------------------------------------------------------------- text half (host logic of the product)
+VOCAB = ["[PAD]", "[UNK]", "[CLS]", "[SEP]", "[MASK]", "no", "acute", "cardio", "##pulmonary", "process", "the", "heart",
+         "is", "normal", "in", "size", "lungs", "are", "clear", "pleural", "effusion", "##s", "2", "mm"]
+
+
+@pytest.fixture()
+def collate_fn(tmp_path):
+    from gloria.config import pretrain_config
+    from gloria.datasets.collate import GloriaCollateFn
+    vocab = tmp_path / "vocab.txt"
+    vocab.write_text("\n".join(VOCAB) + "\n")
+    cfg = pretrain_config("imagenome", batch_size=4)
+    cfg.set_path("model.text.bert_type", str(vocab))
+    cfg.set_path("data.text.word_num", 16)
+    return GloriaCollateFn(cfg, "train", device="cpu")
+
+
+def test_clean_report():
+    from gloria.datasets.collate import clean_report
+    text = "FINDINGS:\n1. The heart is normal in size. 2. No pleural effusions\nLungs are clear. X. café 2mm."
+    # "FINDINGS:" and "X" are one-token sentences: dropped (mimic_for_gloria.py:209-210)
+    assert clean_report(text) == "the heart is normal in size no pleural effusions lungs are clear caf 2mm"
+
+    class First:
+        @staticmethod
+        def randint(a, b):
+            return b
+    assert clean_report(text, full_report=False, rng=First) == "caf 2mm"
+
+
+def test_process_text_ids_and_cap_lens(collate_fn):
+    out = collate_fn.process_text(["No acute cardiopulmonary process.", "1. The heart is normal. 2. Lungs are clear, zzz."], "cpu")
+    ids = out["caption_ids"]
+    assert ids.shape == (2, 16) and out["attention_mask"].shape == (2, 16) and ids.dtype == torch.int64
+    w = {t: i for i, t in enumerate(VOCAB)}
+    assert ids[0, :7].tolist() == [w["[CLS]"], w["no"], w["acute"], w["cardio"], w["##pulmonary"], w["process"], w["[SEP]"]]
+    assert ids[0, 7:].eq(0).all() and out["attention_mask"][0].sum() == 7
+    assert ids[1, :10].tolist() == [w["[CLS]"], w["the"], w["heart"], w["is"], w["normal"], w["lungs"], w["are"], w["clear"],
+                                    w["[UNK]"], w["[SEP]"]]
+    # cap_lens counts tokens not starting with "[" (word pieces included) + 1   (mimic_for_gloria.py:252-254)
+    assert out["cap_lens"] == [5 + 1, 7 + 1]
+    single = collate_fn.process_text(["Lungs are clear."], "cpu")
+    assert single["caption_ids"].shape == (1, 16)
+
+
+def test_crop_offsets_follow_torchvision_rng_order(collate_fn):
+    torch.manual_seed(7)
+    got = collate_fn.crop_offsets(3)
+    torch.manual_seed(7)
+    want = [(int(torch.randint(0, 33, (1,))), int(torch.randint(0, 33, (1,)))) for _ in range(3)]
+    assert got == want
+    collate_fn.split = "valid"
+    assert collate_fn.crop_offsets(2) == [(16, 16)] * 2 == [co.center_crop_offset()] * 2
+
+
+def test_collate_images_needs_the_gpu(collate_fn):
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(RuntimeError):
+        collate_fn.process_img([np.zeros((300, 300), dtype=np.uint8)], "cpu")
+    with pytest.raises(NotImplementedError):
+        collate_fn.process_img([np.zeros((100, 100), dtype=np.uint8)], "cpu")

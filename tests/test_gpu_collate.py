@@ -1,0 +1,106 @@
+"""GPU parity of the collate kernels (glr_image_minmax / glr_collate_images) against the CPU
+restatement oracle/collate_oracle.py: BIT-EXACT (every output is one of 256 fp32 values chosen by integer /
+correctly-rounded arithmetic in a fixed order).  The oracle's cv2 stage is "parity unpinned" (see its header)."""
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import collate_oracle as co
+
+pytestmark = pytest.mark.gpu
+
+# (H, W): 2x2 integer fast path, 4x4 fast path, 3x fast, general both axes, one axis integer, equal size (copy),
+# equal size with padding, tall / wide, full-resolution chest film
+SHAPES = [(512, 512), (1024, 1000), (768, 768), (300, 256), (777, 1033), (512, 501), (256, 256), (256, 200), (3056, 2544),
+          (2544, 3056), (257, 1999)]
+
+
+def images(dtype, seed=0):
+    rng = np.random.default_rng(seed)
+    out = []
+    for h, w in SHAPES:
+        if dtype == np.uint8:
+            a = rng.integers(0, 256, size=(h, w), dtype=np.uint8)
+        elif dtype == np.int16:
+            a = rng.integers(-1024, 3072, size=(h, w)).astype(np.int16)
+        else:
+            a = (rng.standard_normal((h, w)) * 417.3 + 1000).astype(np.float32)
+        # smooth structure on top of the noise so that neighbouring cells differ systematically
+        a = (a * 0.5 + (np.add.outer(np.arange(h), np.arange(w)) % 251) * (0.5 if dtype == np.uint8 else 7)).astype(dtype)
+        out.append(a)
+    return out
+
+
+def offsets(n, seed=3):
+    rng = np.random.default_rng(seed)
+    o = [(int(a), int(b)) for a, b in rng.integers(0, 33, size=(n, 2))]
+    o[0], o[1] = (0, 0), (32, 32)
+    return o
+
+
+@pytest.mark.parametrize("dtype,minmax", [(np.uint8, False), (np.uint8, True), (np.int16, True), (np.float32, True)])
+def test_collate_bit_exact(dtype, minmax):
+    from gloria.datasets.collate import collate_images
+    imgs = images(dtype)
+    offs = offsets(len(imgs))
+    got = collate_images(imgs, offs, 256, 224, "cuda", minmax=minmax).cpu().numpy()
+    u8 = [co.to_u8(a) if minmax else a for a in imgs]
+    want = co.process_img(u8, offs, 256, 224)
+    bad = [i for i in range(len(imgs)) if not np.array_equal(got[i], want[i])]
+    assert not bad, [(SHAPES[i], float(np.abs(got[i] - want[i]).max()) * 127.5) for i in bad]
+
+
+def test_minmax_state_and_constant_image():
+    from gloria import _native as N
+    from gloria.datasets.collate import collate_images
+    # a constant image has max == min: the reference divides 0/0 -> NaN -> uint8 cast; defined here as 0 -> -1.0
+    out = collate_images([np.full((300, 300), 7, dtype=np.int16)], [(16, 16)], minmax=True)
+    assert (out == -1).all()
+    # constant uint8 image without min-max: every resized pixel keeps the value, padding is -1
+    out = collate_images([np.full((400, 300), 200, dtype=np.uint8)], [(16, 16)]).cpu().numpy()
+    dh, dw, top, left = co.resize_plan(400, 300, 256)
+    val = np.float32((np.float32(200) / np.float32(255) - np.float32(0.5)) / np.float32(0.5))
+    cols = np.arange(16, 240)
+    inside = (cols >= left) & (cols < left + dw)
+    assert (out[0, :, :, inside] == val).all() and (out[0, :, :, ~inside] == -1).all()
+    assert N.lib().glr_collate_images(None, None, None, None, 1, 0, 224, None, None) == -1
+
+
+def test_full_size_batch_properties():
+    """BASELINE-sized batch (256 full-resolution 16-bit films would be 4 GB; 64 here): per-image results do not depend
+    on the batch they are in, and channels are equal."""
+    from gloria.datasets.collate import collate_images
+    rng = np.random.default_rng(11)
+    base = [rng.integers(0, 4096, size=s).astype(np.int16) for s in ((3056, 2544), (2544, 3056), (2022, 2022), (1760, 2140))]
+    imgs = [base[i % 4] for i in range(64)]
+    offs = [(i % 33, (7 * i) % 33) for i in range(64)]
+    out = collate_images(imgs, offs, minmax=True)
+    assert torch.equal(out[:, 0], out[:, 1]) and torch.equal(out[:, 0], out[:, 2])
+    for i in (0, 1, 2, 3, 37, 63):
+        single = collate_images([imgs[i]], [offs[i]], minmax=True)
+        assert torch.equal(single[0], out[i])
+    want = co.process_img([co.to_u8(base[2])], [offs[2]])
+    assert np.array_equal(out[2].cpu().numpy(), want[0])
+
+
+def test_get_batch_end_to_end(tmp_path):
+    from gloria.config import pretrain_config
+    from gloria.datasets.collate import GloriaCollateFn
+    vocab = tmp_path / "vocab.txt"
+    words = ["[PAD]", "[UNK]", "[CLS]", "[SEP]", "[MASK]", "the", "heart", "is", "normal", "lungs", "are", "clear", "no", "effusion"]
+    vocab.write_text("\n".join(words) + "\n")
+    cfg = pretrain_config("imagenome", batch_size=3)
+    cfg.set_path("model.text.bert_type", str(vocab))
+    fn = GloriaCollateFn(cfg, "valid", device="cuda")
+    rng = np.random.default_rng(2)
+    raw = [torch.from_numpy(rng.integers(0, 4096, size=s).astype(np.int16)) for s in ((600, 500), (512, 512), (300, 700))]
+    caps = ["The heart is normal.", "The heart is normal. Lungs are clear. No effusion.", "Lungs are clear. No effusion"]
+    instances = [{f"p{i}": {f"s{i}": {"images": {f"d{i}": raw[i]}, "report": caps[i]}}} for i in range(3)]
+    batch = fn(instances)
+    assert batch["cap_lens"].tolist() == [10, 6, 5]                          # sorted descending (mimic_for_gloria.py:95)
+    assert batch["imgs"].shape == (3, 3, 224, 224) and batch["caption_ids"].shape == (3, 97)
+    order = [1, 2, 0]
+    assert [next(iter(i.keys())) for i in batch["instances"]] == [f"p{j}" for j in order]
+    want = co.process_img([co.to_u8(raw[j].numpy()) for j in order], [co.center_crop_offset()] * 3)
+    assert np.array_equal(batch["imgs"].cpu().numpy(), want)

@@ -1,0 +1,45 @@
+"""Micro-benchmark of the collate kernels: B full-resolution 16-bit chest films (3056 x 2544, the
+MIMIC-CXR DICOM size) resident in HBM -> float32 [B, 3, 224, 224].  Prints per-kernel time (HIP events on the
+launch stream) and achieved GB/s on the algorithmic bytes (one read of the source per kernel + the output write)."""
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, "gloria-nlp-project_amd")
+from gloria import _native as N  # noqa: E402
+from gloria.datasets.collate import resize_plan  # noqa: E402
+
+
+def main(B=64, H=3056, W=2544, reps=10):
+    dev = "cuda"
+    L = N.lib()
+    n = H * W
+    src = torch.randint(0, 4096, (B, n), dtype=torch.int16, device=dev)
+    dh, dw, top, left = resize_plan(H, W, 256)
+    desc = torch.tensor([[H, W, dh, dw, top, left, 16, 16]] * B, dtype=torch.int32, device=dev)
+    off = (torch.arange(B, dtype=torch.int64, device=dev) * n * 2)
+    state = torch.empty(B, 2, dtype=torch.int32, device=dev)
+    out = torch.empty(B, 3, 224, 224, device=dev)
+    st = N.stream()
+
+    def mm():
+        N.check(L.glr_image_minmax(N.ptr(src), N.ptr(off), N.ptr(desc), B, 1, N.ptr(state), st), "minmax")
+
+    def col():
+        N.check(L.glr_collate_images(N.ptr(src), N.ptr(off), N.ptr(desc), N.ptr(state), B, 1, 224, N.ptr(out), st), "collate")
+
+    for name, fn, nbytes in (("glr_image_minmax", mm, B * n * 2), ("glr_collate_images", col, B * n * 2 * (224 / 256) ** 2 + out.numel() * 4)):
+        fn(); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record(); torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        print(f"{name}: B={B} {H}x{W} i16  {ms:.3f} ms  algorithmic {nbytes / 1e9:.3f} GB -> {nbytes / ms / 1e6:.0f} GB/s "
+              f"({nbytes / ms / 1e6 / 8000:.3f} of 8 TB/s)")
+
+
+if __name__ == "__main__":
+    main(*(int(a) for a in sys.argv[1:]))
