@@ -8,8 +8,9 @@
 //
 // Two kernels, both HBM-bound byte work (no MFMA):
 //   k_image_minmax   one read of the ragged source batch -> per-image min / max (order-preserving uint keys, atomics)
-//   k_collate        one thread per OUTPUT pixel of the crop window: it evaluates cv2's INTER_AREA cell of that
-//                    pixel straight from the source (quantising each source pixel to uint8 on the fly), so the
+//   k_collate        one workgroup per output row of the crop window, one thread per OUTPUT pixel: the source rows
+//                    under that output row are staged through LDS (16-byte coalesced loads, quantised to uint8 on
+//                    the way) and each thread evaluates cv2's INTER_AREA cell of its pixel from LDS, so the
 //                    uint8 image, the resized image and the padded 256x256 frame are never materialised and only
 //                    the source pixels under the crop window are read.  Every fp32 / fp64 operation is written
 //                    with explicit rounding (no FMA contraction) in the order OpenCV's scalar code performs it,
@@ -61,14 +62,22 @@ __global__ __launch_bounds__(256) void k_image_minmax(const unsigned char* __res
   if ((off & 15) == 0) {                       // 16-byte vector loads over the aligned body
     const long long nv = n / VEC;
     const uint4* pv = reinterpret_cast<const uint4*>(p);
-    for (long long i = tid; i < nv; i += nthr) {
-      uint4 raw = pv[i];
-      const T* e = reinterpret_cast<const T*>(&raw);
+    for (long long i = tid; i < nv; i += 4 * nthr) {           // four independent 16-byte loads in flight per thread
+      uint4 raw[4];
 #pragma unroll
-      for (int j = 0; j < VEC; ++j) {
-        float v = (float)e[j];
-        mn = fminf(mn, v);
-        mx = fmaxf(mx, v);
+      for (int u = 0; u < 4; ++u) {
+        const long long iu = i + u * nthr;
+        raw[u] = pv[iu < nv ? iu : i];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const T* e = reinterpret_cast<const T*>(&raw[u]);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          float v = (float)e[j];
+          mn = fminf(mn, v);
+          mx = fmaxf(mx, v);
+        }
       }
     }
     done = nv * VEC;
@@ -128,82 +137,215 @@ __device__ __forceinline__ Taps make_taps(int d, int ssize, double scale) {
   return t;
 }
 
+template <typename T> struct IsIntSrc { static constexpr bool value = true; };
+template <> struct IsIntSrc<float> { static constexpr bool value = false; };
+
 template <typename T, bool MINMAX>
 struct Quant {
-  float mn, range;
+  float mn, range, rcp;
+  __device__ __forceinline__ void set(float lo, float hi) {
+    mn = lo;
+    range = sub_(hi, lo);
+    // loop-invariant half of the compiler's own fp32 division (v_rcp_f32 + one Newton step), see quotient()
+    const float y = __builtin_amdgcn_rcpf(range);
+    rcp = __builtin_fmaf(__builtin_fmaf(-range, y, 1.0f), y, y);
+  }
+  // n / range, bit-identical to the `/` operator.  For 8/16-bit sources n and range are integers below 2^17, so
+  // the v_div_scale / v_div_fixup steps of the compiler's expansion are identities and the division reduces to its
+  // fma chain with the reciprocal hoisted out of the per-pixel path (5 instructions instead of 13).
+  __device__ __forceinline__ float quotient(float n) const {
+    if (!IsIntSrc<T>::value) return div_(n, range);
+    const float q0 = mul_(n, rcp);
+    const float e0 = __builtin_fmaf(-range, q0, n);
+    const float q1 = __builtin_fmaf(e0, rcp, q0);
+    const float e1 = __builtin_fmaf(-range, q1, n);
+    return __builtin_fmaf(e1, rcp, q1);
+  }
   __device__ __forceinline__ float operator()(T raw) const {
     if (!MINMAX) return (float)raw;                       // already the 8-bit image
-    float y = mul_(div_(sub_((float)raw, mn), range), 255.0f);
+    float y = mul_(quotient(sub_((float)raw, mn)), 255.0f);
     int q = (int)y;                                       // C cast: truncation (NaN when max == min -> 0)
     q = y != y ? 0 : min(max(q, 0), 255);
     return (float)q;
   }
 };
 
+// one source row as the resampler sees it: quantised pixel `col` as a float
+template <typename T, bool MINMAX>
+struct GlobalRow {
+  const T* row;
+  Quant<T, MINMAX> q;
+  __device__ __forceinline__ float at(int col) const { return q(row[col]); }
+};
+struct LdsRow {
+  const unsigned char* row;                 // staged, already quantised bytes; row[col] valid for the block's span
+  __device__ __forceinline__ float at(int col) const { return (float)row[col]; }
+};
+template <typename T, bool MINMAX>
+struct GlobalRows {
+  const T* S;
+  int W;
+  Quant<T, MINMAX> q;
+  __device__ __forceinline__ GlobalRow<T, MINMAX> operator()(int sy) const {
+    return GlobalRow<T, MINMAX>{S + (long long)sy * W, q};
+  }
+};
+struct LdsRows {                            // rows [r, r + nr) staged at `pitch` bytes each, vector aligned per row
+  const unsigned char* lds;
+  int r, pitch, W, c_lo, vmask;
+  __device__ __forceinline__ LdsRow operator()(int sy) const {
+    const int mis = (int)(((long long)sy * W + c_lo) & vmask);
+    return LdsRow{lds + (sy - r) * pitch + mis - c_lo};
+  }
+};
+
+// running state of one output pixel while its source rows are visited in order
+struct Acc {
+  float total;
+  bool first_row;
+  int isum;
+};
+
+// rows [ra, rb) of the cell of one output pixel, in OpenCV's order (mode 0 copy, 1 integer scale, 2 general)
+template <typename RowOf>
+__device__ __forceinline__ Acc accumulate(const RowOf row_of, int ra, int rb, int mode, int dx, int ix, const Taps tx,
+                                          const Taps ty, Acc a) {
+  for (int sy = ra; sy < rb; ++sy) {
+    const auto row = row_of(sy);
+    if (mode == 0) {
+      a.isum = (int)row.at(dx);
+    } else if (mode == 1) {
+      for (int c = 0; c < ix; ++c) a.isum += (int)row.at(dx * ix + c);
+    } else {
+      const float beta = sy < ty.s1 ? ty.a_first : (sy < ty.s2 ? ty.a_mid : ty.a_last);
+      float buf = 0.f;
+      if (tx.has_first) buf = add_(buf, mul_(row.at(tx.s1 - 1), tx.a_first));
+      for (int sx = tx.s1; sx < tx.s2; ++sx) buf = add_(buf, mul_(row.at(sx), tx.a_mid));
+      if (tx.has_last) buf = add_(buf, mul_(row.at(tx.s2), tx.a_last));
+      const float term = mul_(beta, buf);
+      a.total = a.first_row ? term : add_(a.total, term);
+      a.first_row = false;
+    }
+  }
+  return a;
+}
+
+constexpr int LDS_BYTES = 40960;            // staged source rows of one output row (4 workgroups per CU)
+
+// One workgroup per (output row, image).  The source rows under that output row are staged into LDS with 16-byte
+// coalesced loads (all loads of a thread in flight together), quantised to uint8 once per source pixel, and every
+// thread then walks the taps of its own output pixel out of LDS in OpenCV's summation order.  Rows are staged in
+// chunks when they do not fit; images whose packed offset is not 16-byte aligned, or whose single-row span exceeds
+// LDS, take the same arithmetic straight from global memory.
 template <typename T, bool MINMAX>
 __global__ __launch_bounds__(256) void k_collate(const unsigned char* __restrict__ src,
                                                  const long long* __restrict__ offset, const int* __restrict__ desc,
                                                  const unsigned* __restrict__ state, int crop,
                                                  float* __restrict__ out) {
+  constexpr int VEC = Src<T>::VEC;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
   const int b = blockIdx.y;
   const int oy = blockIdx.x, ox = threadIdx.x;
-  if (ox >= crop) return;
   const int* ds = desc + 8 * b;
   const int H = ds[0], W = ds[1], dH = ds[2], dW = ds[3];
   const int dy = ds[6] + oy - ds[4], dx = ds[7] + ox - ds[5];     // position inside the resized image
-  const T* S = reinterpret_cast<const T*>(src + offset[b]);
+  const long long off = offset[b];
+  const T* S = reinterpret_cast<const T*>(src + off);
   Quant<T, MINMAX> q;
-  q.mn = 0.f;
-  q.range = 1.f;
-  if (MINMAX) {
-    q.mn = key2f(state[2 * b]);
-    q.range = sub_(key2f(state[2 * b + 1]), q.mn);
-  }
+  q.set(0.f, 1.f);
+  if (MINMAX) q.set(key2f(state[2 * b]), key2f(state[2 * b + 1]));
+  const bool active = ox < crop;
+  const bool ok = active && dx >= 0 && dx < dW;
+  const int dx_lo = max(0, ds[7] - ds[5]), dx_hi = min(dW, ds[7] + crop - ds[5]);   // columns this row needs
   int v = 0;                                                       // zero padding outside the resized image
-  if (dy >= 0 && dy < dH && dx >= 0 && dx < dW) {
-    if (dH == H && dW == W) {
-      v = (int)q(S[(long long)dy * W + dx]);                       // cv2.resize copies when the sizes are equal
-    } else {
-      const double scale_x = div_(1.0, div_((double)dW, (double)W));
-      const double scale_y = div_(1.0, div_((double)dH, (double)H));
-      const int ix = __double2int_rn(scale_x), iy = __double2int_rn(scale_y);
-      if (fabs(scale_x - ix) < GLR_DBL_EPS && fabs(scale_y - iy) < GLR_DBL_EPS) {
-        int sum = 0;                                               // integer scale: exact box sums
-        for (int r = 0; r < iy; ++r) {
-          const T* row = S + (long long)(dy * iy + r) * W + dx * ix;
-          for (int c = 0; c < ix; ++c) sum += (int)q(row[c]);
+  if (dy >= 0 && dy < dH && dx_hi > dx_lo) {                       // uniform over the workgroup
+    int mode = 0, ix = 1, iy = 1;
+    double scale_x = 1.0, scale_y = 1.0;
+    if (!(dH == H && dW == W)) {                                   // cv2.resize copies when the sizes are equal
+      scale_x = div_(1.0, div_((double)dW, (double)W));
+      scale_y = div_(1.0, div_((double)dH, (double)H));
+      ix = __double2int_rn(scale_x);
+      iy = __double2int_rn(scale_y);
+      mode = (fabs(scale_x - ix) < GLR_DBL_EPS && fabs(scale_y - iy) < GLR_DBL_EPS) ? 1 : 2;
+    }
+    Taps ty = {}, tx = {};
+    int r0 = dy, r1 = dy + 1, c_lo = dx_lo, c_hi = dx_hi;
+    if (mode == 1) {
+      r0 = dy * iy;
+      r1 = r0 + iy;
+      c_lo = dx_lo * ix;
+      c_hi = dx_hi * ix;
+    } else if (mode == 2) {
+      ty = make_taps(dy, H, scale_y);
+      r0 = ty.has_first ? ty.s1 - 1 : ty.s1;
+      r1 = ty.has_last ? ty.s2 + 1 : ty.s2;
+      c_lo = max(0, (int)floor(mul_((double)dx_lo, scale_x)) - 1);
+      c_hi = min(W, (int)ceil(mul_((double)dx_hi, scale_x)) + 1);
+      if (ok) tx = make_taps(dx, W, scale_x);
+    }
+    const int pitch = (c_hi - c_lo + 2 * VEC + 15) & ~15;
+    const int R = LDS_BYTES / pitch;
+    Acc acc = {0.f, true, 0};
+    if ((off & 15) == 0 && R > 0) {
+      const int vpr = pitch / VEC;                                 // 16-byte vectors staged per row
+      const long long n_pad = ((long long)H * W + VEC - 1) / VEC * VEC;   // images are padded to 16 bytes in `src`
+      for (int r = r0; r < r1; r += R) {
+        const int nr = min(R, r1 - r);
+        if (r != r0) __syncthreads();
+        for (int v0 = ox; v0 < nr * vpr; v0 += 4 * 256) {         // up to four loads in flight per thread
+          uint4 raw[4];
+          int where[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int vi = v0 + u * 256;
+            where[u] = -1;
+            if (vi < nr * vpr) {
+              const int rl = vi / vpr, k = vi - rl * vpr;
+              const long long idx = (((long long)(r + rl) * W + c_lo) & ~(long long)(VEC - 1)) + (long long)k * VEC;
+              if (idx + VEC <= n_pad) {
+                raw[u] = *reinterpret_cast<const uint4*>(S + idx);
+                where[u] = rl * pitch + k * VEC;
+              }
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            if (where[u] >= 0) {
+              const T* e = reinterpret_cast<const T*>(&raw[u]);
+              unsigned w[VEC / 4] = {};
+#pragma unroll
+              for (int j = 0; j < VEC; ++j) w[j / 4] |= (unsigned)(int)q(e[j]) << (8 * (j % 4));
+              unsigned* d = reinterpret_cast<unsigned*>(lds + where[u]);
+#pragma unroll
+              for (int j = 0; j < VEC / 4; ++j) d[j] = w[j];
+            }
+          }
         }
+        __syncthreads();
+        if (ok) acc = accumulate(LdsRows{lds, r, pitch, W, c_lo, VEC - 1}, r, r + nr, mode, dx, ix, tx, ty, acc);
+      }
+    } else if (ok) {
+      acc = accumulate(GlobalRows<T, MINMAX>{S, W, q}, r0, r1, mode, dx, ix, tx, ty, acc);
+    }
+    if (ok) {
+      if (mode == 0) {
+        v = acc.isum;
+      } else if (mode == 1) {
         if (ix == 2 && iy == 2) {
-          v = (sum + 2) >> 2;                                      // OpenCV's 8u 2x2 SIMD rounding
+          v = (acc.isum + 2) >> 2;                                 // OpenCV's 8u 2x2 SIMD rounding
         } else {
           const float inv = div_(1.0f, (float)(ix * iy));
-          v = __float2int_rn(mul_((float)sum, inv));
+          v = __float2int_rn(mul_((float)acc.isum, inv));
         }
       } else {
-        const Taps tx = make_taps(dx, W, scale_x);
-        const Taps ty = make_taps(dy, H, scale_y);
-        float total = 0.f;
-        bool first_row = true;
-        const int r0 = ty.has_first ? ty.s1 - 1 : ty.s1;
-        const int r1 = ty.has_last ? ty.s2 + 1 : ty.s2;
-        for (int sy = r0; sy < r1; ++sy) {
-          const float beta = sy < ty.s1 ? ty.a_first : (sy < ty.s2 ? ty.a_mid : ty.a_last);
-          const T* row = S + (long long)sy * W;
-          float buf = 0.f;
-          if (tx.has_first) buf = add_(buf, mul_(q(row[tx.s1 - 1]), tx.a_first));
-          for (int sx = tx.s1; sx < tx.s2; ++sx) buf = add_(buf, mul_(q(row[sx]), tx.a_mid));
-          if (tx.has_last) buf = add_(buf, mul_(q(row[tx.s2]), tx.a_last));
-          const float term = mul_(beta, buf);
-          total = first_row ? term : add_(total, term);
-          first_row = false;
-        }
-        v = __float2int_rn(total);                                 // saturate_cast<uchar>: round half to even
+        v = __float2int_rn(acc.total);                             // saturate_cast<uchar>: round half to even
       }
       v = min(max(v, 0), 255);
     }
   }
-  const float t = div_((float)v, 255.0f);                      // ToTensor
-  const float o = div_(sub_(t, 0.5f), 0.5f);              // Normalize(0.5, 0.5)
+  if (!active) return;
+  const float t = div_((float)v, 255.0f);                          // ToTensor
+  const float o = div_(sub_(t, 0.5f), 0.5f);                       // Normalize(0.5, 0.5)
   const long long plane = (long long)crop * crop;
   float* dst = out + (long long)b * 3 * plane + (long long)oy * crop + ox;
   dst[0] = o;

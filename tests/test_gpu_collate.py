@@ -104,3 +104,28 @@ def test_get_batch_end_to_end(tmp_path):
     assert [next(iter(i.keys())) for i in batch["instances"]] == [f"p{j}" for j in order]
     want = co.process_img([co.to_u8(raw[j].numpy()) for j in order], [co.center_crop_offset()] * 3)
     assert np.array_equal(batch["imgs"].cpu().numpy(), want)
+
+
+def test_rows_staged_in_chunks_and_unaligned_fallback():
+    """scale 20 (5120 x 4400): the ~22 source rows of an output row do not fit the 40 KB LDS stage at once -> chunked
+    staging; a packed offset that is not 16-byte aligned takes the same arithmetic straight from global memory."""
+    from gloria import _native as N
+    from gloria.datasets.collate import collate_images, resize_plan
+    rng = np.random.default_rng(4)
+    big = rng.integers(0, 256, size=(5120, 4400), dtype=np.uint8)
+    offs = [(5, 9)]
+    got = collate_images([big], offs).cpu().numpy()
+    assert np.array_equal(got, co.process_img([big], offs))
+    # direct C-ABI call with a 2-byte shifted int16 image
+    img = rng.integers(-500, 3000, size=(700, 900)).astype(np.int16)
+    buf = torch.zeros(img.size * 2 + 64, dtype=torch.uint8, device="cuda")
+    buf[2:2 + img.size * 2] = torch.from_numpy(img.reshape(-1).view(np.uint8)).cuda()
+    dh, dw, top, left = resize_plan(700, 900, 256)
+    desc = torch.tensor([700, 900, dh, dw, top, left, 11, 3], dtype=torch.int32, device="cuda")
+    off = torch.tensor([2], dtype=torch.int64, device="cuda")
+    state = torch.empty(2, dtype=torch.int32, device="cuda")
+    out = torch.empty(1, 3, 224, 224, device="cuda")
+    L = N.lib()
+    N.check(L.glr_image_minmax(N.ptr(buf), N.ptr(off), N.ptr(desc), 1, 1, N.ptr(state), N.stream()), "minmax")
+    N.check(L.glr_collate_images(N.ptr(buf), N.ptr(off), N.ptr(desc), N.ptr(state), 1, 1, 224, N.ptr(out), N.stream()), "collate")
+    assert np.array_equal(out.cpu().numpy(), co.process_img([co.to_u8(img)], [(11, 3)]))

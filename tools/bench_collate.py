@@ -6,7 +6,7 @@ import sys
 import numpy as np
 import torch
 
-sys.path.insert(0, "gloria-nlp-project_amd")
+sys.path.insert(0, __import__("os").path.join(__import__("os").path.dirname(__import__("os").path.abspath(__file__)), "..", "gloria-nlp-project_amd"))
 from gloria import _native as N  # noqa: E402
 from gloria.datasets.collate import resize_plan  # noqa: E402
 
