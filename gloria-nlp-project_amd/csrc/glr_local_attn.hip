@@ -159,7 +159,7 @@ __device__ __forceinline__ void wg_barrier() {
 
 constexpr int CHB = 64;     // bytes of K per ring row (both dtypes): bf16 = 2 k-steps of 16, fp32 = 2 of 8
 constexpr int NBUF = 4;     // ring depth
-constexpr int PD = 3;       // chunks issued ahead of the one being consumed
+[[maybe_unused]] constexpr int PD = 3;       // chunks issued ahead of the one being consumed (documentation of the ring depth)
 
 // acc[j] (+)= A(tw words x K) . Bt(brows x K)^T for this wave's blocks.
 //   A_RES = false: A rows stream from `asrc` (tw rows per 64-row tile block, apitch = K bytes per row) together with B.
@@ -1207,7 +1207,7 @@ __global__ void __launch_bounds__(NTHR) k_local_attn_pair(LaParams p) {
 // Handles ordinary tiles with at most T4_MAXSEG sentences (the pair kernel keeps the rest).
 constexpr int T4_MAXSEG = 8;
 constexpr int T4_NT = 256;
-constexpr int T4_PF = 3;                          // chunks of fragments in flight
+[[maybe_unused]] constexpr int T4_PF = 3;         // chunks of fragments in flight
 
 struct T4Frags { bf16x8 a0[2], a1[2], b[2][3]; };
 

@@ -6,10 +6,11 @@ Collectives on the path:
   * all-gather of text embeddings (word-level [B, D, L] and global [B, D]) with a reduce-scatter
     of their gradients in backward;
   * all-gather of the similarity block-rows (256 KB at B = 256) for the column cross entropy;
-  * bucketed SUM all-reduce of parameter gradients (flat buckets, launched as soon as a bucket's
-    gradients are ready would be the next step; round 1 launches all buckets asynchronously after
-    backward and waits once).  xGMI is point-to-point, so buckets are large (64 MiB) to amortise
-    per-collective latency and let RCCL use all 7 links.
+  * bucketed SUM all-reduce of parameter gradients: `GradReducer` keeps every `.grad` as a view into a
+    flat bucket and launches a bucket's all-reduce from a post-accumulate hook as soon as its gradients
+    are ready, overlapped with the rest of backward (`DistContext.allreduce_grads` is the simple
+    after-backward form kept for the CPU tests).  xGMI is point-to-point, so buckets are large (64 MiB)
+    to amortise per-collective latency and let RCCL use all 7 links.
 The loss every rank differentiates is the GLOBAL-batch mean, so gradients are summed, not averaged.
 """
 

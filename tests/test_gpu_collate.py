@@ -129,3 +129,13 @@ def test_rows_staged_in_chunks_and_unaligned_fallback():
     N.check(L.glr_image_minmax(N.ptr(buf), N.ptr(off), N.ptr(desc), 1, 1, N.ptr(state), N.stream()), "minmax")
     N.check(L.glr_collate_images(N.ptr(buf), N.ptr(off), N.ptr(desc), N.ptr(state), 1, 1, 224, N.ptr(out), N.stream()), "collate")
     assert np.array_equal(out.cpu().numpy(), co.process_img([co.to_u8(img)], [(11, 3)]))
+
+
+def test_wide_range_int16_takes_the_arithmetic_quantiser():
+    """more than 8192 grey levels: no per-workgroup lookup table, the exact division runs per staged pixel"""
+    from gloria.datasets.collate import collate_images
+    rng = np.random.default_rng(9)
+    imgs = [rng.integers(-30000, 30000, size=s).astype(np.int16) for s in ((777, 1033), (512, 512), (1024, 1000), (300, 256))]
+    offs = [(1, 2), (30, 31), (16, 16), (0, 32)]
+    got = collate_images(imgs, offs, minmax=True).cpu().numpy()
+    assert np.array_equal(got, co.process_img([co.to_u8(a) for a in imgs], offs))
