@@ -13,8 +13,10 @@ image half on the GPU.
         local directory / vocab file or a tokenizer object is passed in)
   get_batch / __call__          :66-108   sort by caption length (descending), permute every field alike
 
-Not built: segmentation labels from bounding boxes (:110-118, `bboxes` raises), the random flip / affine / colour
-transforms of builder.py:167-186 (unused by configs/imagenome_pretrain_config.yaml), images smaller than `imsize`
+  get_segmentation_labels       :110-118  boxes -> bool [B, crop, crop] labels; host integers / tap tables instead of
+        one full-resolution mask image per box (see `resized_box_mask`)
+
+Not built: the random flip / affine / colour transforms of builder.py:167-186 (unused by configs/imagenome_pretrain_config.yaml), images smaller than `imsize`
 (cv2 would upscale with its bilinear branch).  There is no CPU path: process_img needs the HIP library and a GPU.
 """
 
@@ -97,6 +99,87 @@ def collate_images(images, crop_offsets, scale=256, crop=224, device="cuda", min
     N.check(L.glr_collate_images(N.ptr(src), N.ptr(off_d), N.ptr(desc_d), N.ptr(state), len(arrs), code, crop,
                                  N.ptr(out), N.stream()), "glr_collate_images")
     return out
+
+
+# ---------------------------------------------------------------- segmentation labels from bounding boxes (host)
+# The reference renders every box as a full-size 0/255 mask, sends it through process_img (cv2 resize, pad, crop,
+# normalise), thresholds `> 0` on the NORMALISED tensor (i.e. grey level >= 128), takes the bounding box of what is
+# left and ORs the boxes into a crop x crop label (mimic_for_gloria.py:13-55, 110-118).  The resized mask of a
+# rectangle is separable, so the same numbers come out of the tap tables directly: O(dst_h * dst_w) host work per box
+# instead of a full-resolution image, with OpenCV's fp32 summation order kept (zero terms add +0.0 exactly).
+_DBL_EPSILON = 2.220446049250313e-16
+
+
+def _area_taps(ssize, dsize, scale):
+    """OpenCV computeResizeAreaTab as dense tables: source index and fp32 weight of every ordered tap of every
+    destination index (absent taps: weight 0 on index 0)."""
+    rows = []
+    for d in range(dsize):
+        fs1 = d * scale
+        fs2 = fs1 + scale
+        cell = min(scale, ssize - fs1)
+        s2 = min(math.floor(fs2), ssize - 1)
+        s1 = min(math.ceil(fs1), s2)
+        t = []
+        if s1 - fs1 > 1e-3:
+            t.append((s1 - 1, (s1 - fs1) / cell))
+        t.extend((sx, 1.0 / cell) for sx in range(s1, s2))
+        if fs2 - s2 > 1e-3:
+            t.append((s2, min(min(fs2 - s2, 1.0), cell) / cell))
+        rows.append(t)
+    n = max(len(t) for t in rows)
+    idx = np.zeros((dsize, n), dtype=np.int64)
+    alpha = np.zeros((dsize, n), dtype=np.float32)
+    for d, t in enumerate(rows):
+        for k, (si, a) in enumerate(t):
+            idx[d, k], alpha[d, k] = si, np.float32(a)
+    return idx, alpha
+
+
+def resized_box_mask(h, w, dh, dw, box):
+    """cv2.resize(mask, (dw, dh), INTER_AREA) of the 0/255 mask of `box` = [x0, y0, x1, y1] (inclusive), uint8 [dh, dw]."""
+    x0, y0, x1, y1 = (int(c) for c in box)
+    cols, rows = np.arange(w), np.arange(h)
+    in_x, in_y = (cols >= x0) & (cols <= x1), (rows >= y0) & (rows <= y1)
+    if (dh, dw) == (h, w):
+        return (np.outer(in_y, in_x) * 255).astype(np.uint8)
+    scale_x, scale_y = 1.0 / (float(dw) / w), 1.0 / (float(dh) / h)
+    ix, iy = int(np.rint(scale_x)), int(np.rint(scale_y))
+    if abs(scale_x - ix) < _DBL_EPSILON and abs(scale_y - iy) < _DBL_EPSILON:
+        cnt = np.outer(in_y[:dh * iy].reshape(dh, iy).sum(1), in_x[:dw * ix].reshape(dw, ix).sum(1)).astype(np.int32) * 255
+        if ix == 2 and iy == 2:
+            return ((cnt + 2) >> 2).astype(np.uint8)
+        return np.clip(np.rint(cnt.astype(np.float32) * np.float32(1.0 / (ix * iy))), 0, 255).astype(np.uint8)
+    xi, xa = _area_taps(w, dw, scale_x)
+    yi, ya = _area_taps(h, dh, scale_y)
+    bx = np.zeros(dw, dtype=np.float32)                       # one in-box source row, resampled along x
+    for k in range(xi.shape[1]):
+        bx = bx + np.where(in_x[xi[:, k]], np.float32(255), np.float32(0)) * xa[:, k]
+    total = None
+    for j in range(yi.shape[1]):
+        buf = np.where(in_y[yi[:, j]][:, None], bx[None, :], np.float32(0))
+        term = ya[:, j, None] * buf
+        total = term if total is None else total + term
+    return np.clip(np.rint(total), 0, 255).astype(np.uint8)
+
+
+def resized_box(h, w, box, scale, crop, crop_offset):
+    """process_bboxes (mimic_for_gloria.py:45-55) for one box: [xmin, ymin, xmax, ymax] in the crop window, or
+    [-1, -1, -1, -1] when nothing reaches grey level 128.  Boxes that are empty or cover the whole image make the
+    reference divide 0 / 0 in `normalize`; they count as empty here."""
+    x0, y0, x1, y1 = (int(c) for c in box)
+    x0, y0, x1, y1 = max(x0, 0), max(y0, 0), min(x1, w - 1), min(y1, h - 1)
+    if x1 < x0 or y1 < y0 or (x0 == 0 and y0 == 0 and x1 == w - 1 and y1 == h - 1):
+        return [-1, -1, -1, -1]
+    dh, dw, top, left = resize_plan(h, w, scale)
+    frame = np.zeros((scale, scale), dtype=bool)
+    frame[top:top + dh, left:left + dw] = resized_box_mask(h, w, dh, dw, (x0, y0, x1, y1)) >= 128   # (v/255 - .5)/.5 > 0
+    cy, cx = crop_offset
+    win = frame[cy:cy + crop, cx:cx + crop]
+    if not win.any():
+        return [-1, -1, -1, -1]
+    ys, xs = np.nonzero(win.any(1))[0], np.nonzero(win.any(0))[0]
+    return [int(xs[0]), int(ys[0]), int(xs[-1]), int(ys[-1])]
 
 
 def clean_report(text, full_report=True, rng=random):
@@ -186,10 +269,23 @@ class GloriaCollateFn:
         return out
 
     # ---- batch
+    def get_segmentation_labels(self, bboxes, original_shapes, new_shape, device):
+        """mimic_for_gloria.py:110-118.  Every box draws its own crop window, in the reference's order (its masks
+        go through process_img, whose transform contains the RandomCrop)."""
+        labels = torch.zeros((len(bboxes),) + tuple(new_shape), dtype=torch.bool)
+        for b, (bbs, (h, w)) in enumerate(zip(bboxes, original_shapes)):
+            for box, off in zip(bbs, self.crop_offsets(len(bbs))):
+                xa, ya, xb, yb = resized_box(h, w, box, self.scale, self.crop, off)
+                if xa >= 0:
+                    labels[b, ya:yb + 1, xa:xb + 1] = True
+        return labels.to(device)
+
     def get_batch(self, images, captions, instances=None, sort=True, bboxes=None, minmax=None):
-        if bboxes is not None:
-            raise NotImplementedError("segmentation labels from bounding boxes (mimic_for_gloria.py:110-118) are not built")
         imgs = self.process_img(images, self.device, minmax)
+        seg_labels = None
+        if bboxes is not None:
+            shapes = [tuple(im.shape) for im in images]
+            seg_labels = self.get_segmentation_labels(bboxes, shapes, (self.crop, self.crop), self.device)
         cap = self.process_text(captions, self.device)
         lens = torch.tensor(cap["cap_lens"])
         if sort:
@@ -200,6 +296,8 @@ class GloriaCollateFn:
         batch = {k: v[order] for k, v in cap.items() if k != "cap_lens"}
         batch["cap_lens"] = lens
         batch["imgs"] = imgs[order]
+        if seg_labels is not None:
+            batch["segmentation_labels"] = seg_labels[order]
         if instances is not None:
             batch["instances"] = [instances[i] for i in order.tolist()]
         return batch

@@ -156,3 +156,74 @@ def test_collate_images_needs_the_gpu(collate_fn):
         collate_fn.process_img([np.zeros((300, 300), dtype=np.uint8)], "cpu")
     with pytest.raises(NotImplementedError):
         collate_fn.process_img([np.zeros((100, 100), dtype=np.uint8)], "cpu")
+
+
+# ---------------------------------------------------------------- segmentation labels from boxes (host logic)
+def _label_by_rendering(shape, boxes, offs):
+    """the reference's route (mimic_for_gloria.py:45-55, 110-118) through the oracle: render each box as a full-size
+    0/255 mask, process_img it, threshold the normalised tensor at > 0, take the bounding box, OR the boxes"""
+    label = np.zeros((224, 224), dtype=bool)
+    found = []
+    for box, off in zip(boxes, offs):
+        mask = np.zeros(shape, dtype=np.uint8)
+        mask[box[1]:box[3] + 1, box[0]:box[2] + 1] = 255
+        m = co.process_img([mask], [off])[0, 0] > 0
+        if m.any():
+            ys, xs = np.nonzero(m.any(1))[0], np.nonzero(m.any(0))[0]
+            found.append([int(xs[0]), int(ys[0]), int(xs[-1]), int(ys[-1])])
+            label[ys[0]:ys[-1] + 1, xs[0]:xs[-1] + 1] = True
+        else:
+            found.append([-1, -1, -1, -1])
+    return label, found
+
+
+@pytest.mark.parametrize("shape", [(777, 1033), (512, 512), (1024, 1000), (256, 200), (300, 256), (1900, 1500)])
+def test_boxes_to_labels_match_rendered_masks(shape, collate_fn):
+    from gloria.datasets.collate import resized_box
+    h, w = shape
+    rng = np.random.default_rng(h + w)
+    boxes = []
+    for _ in range(6):
+        x0, y0 = int(rng.integers(0, w - 2)), int(rng.integers(0, h - 2))
+        boxes.append([x0, y0, int(rng.integers(x0, w)), int(rng.integers(y0, h))])
+    boxes += [[0, 0, 3, 3], [w - 2, h - 2, w - 1, h - 1], [w // 3, h // 3, w // 3, h // 3]]      # corners, a single pixel
+    offs = [(int(a), int(b)) for a, b in rng.integers(0, 33, size=(len(boxes), 2))]
+    want_label, want_boxes = _label_by_rendering(shape, boxes, offs)
+    got_boxes = [resized_box(h, w, b, 256, 224, o) for b, o in zip(boxes, offs)]
+    assert got_boxes == want_boxes
+    # through the collate object: the crop windows come from torch's RNG in the reference's order
+    collate_fn.split = "train"
+    torch.manual_seed(3)
+    offs2 = collate_fn.crop_offsets(len(boxes))
+    torch.manual_seed(3)
+    got = collate_fn.get_segmentation_labels([boxes], [shape], (224, 224), "cpu")
+    assert got.dtype == torch.bool and got.shape == (1, 224, 224)
+    assert np.array_equal(got[0].numpy(), _label_by_rendering(shape, boxes, offs2)[0])
+
+
+def test_degenerate_boxes_are_empty():
+    from gloria.datasets.collate import resized_box
+    assert resized_box(600, 500, [0, 0, 499, 599], 256, 224, (16, 16)) == [-1, -1, -1, -1]      # whole image: 0/0 in the reference
+    assert resized_box(600, 500, [10, 10, 5, 5], 256, 224, (16, 16)) == [-1, -1, -1, -1]
+    assert resized_box(3000, 2500, [100, 100, 101, 101], 256, 224, (16, 16)) == [-1, -1, -1, -1]  # < half a pixel after resizing
+
+
+def test_call_with_sentence_instances_builds_sorted_labels(collate_fn, monkeypatch):
+    """__call__ on ImaGenome-style sentence instances (mimic_for_gloria.py:66-84): labels follow the caption-length
+    sort like every other field.  The image kernels need a GPU, so process_img is stubbed here."""
+    collate_fn.split = "valid"
+    monkeypatch.setattr(collate_fn, "process_img", lambda images, device, minmax=None: torch.zeros(len(images), 3, 224, 224))
+    raw = [torch.zeros(600, 500, dtype=torch.int16), torch.zeros(512, 512, dtype=torch.int16)]
+    boxes = [[[50, 60, 300, 400]], [[0, 0, 255, 255], [256, 256, 511, 511]]]
+    sents = ["The heart is normal.", "Lungs are clear. No pleural effusions."]
+    instances = [{f"p{i}": {f"s{i}": {"images": {f"d{i}": raw[i]}, "sentence": sents[i], "sent_id": 0,
+                                     "objects": {f"d{i}": {"sent_to_bboxes": [{"coords_original": boxes[i]}]}}}}}
+                 for i in range(2)]
+    batch = collate_fn(instances)
+    assert batch["cap_lens"].tolist() == [8, 5]          # "effusions" is two word pieces
+    lab = batch["segmentation_labels"]
+    assert lab.shape == (2, 224, 224) and lab.dtype == torch.bool
+    want0, _ = _label_by_rendering((512, 512), boxes[1], [(16, 16)] * 2)          # longer caption first
+    want1, _ = _label_by_rendering((600, 500), boxes[0], [(16, 16)])
+    assert np.array_equal(lab[0].numpy(), want0) and np.array_equal(lab[1].numpy(), want1)
+    assert [next(iter(i.keys())) for i in batch["instances"]] == ["p1", "p0"]
