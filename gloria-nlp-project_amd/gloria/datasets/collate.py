@@ -317,3 +317,18 @@ class GloriaCollateFn:
                 captions.append(inst["report"])
         return self.get_batch(images, captions, instances=instances if self.include_instances else None,
                               bboxes=bboxes if len(bboxes) > 0 else None, minmax=True)
+
+
+def multimodal_collate_fn(batch):
+    """The CheXpert-path collate of the reference (gloria/datasets/pretraining_dataset.py:250-282): samples are
+    (img [3, H, W], tokenizer output, cap_len, path); every tensor field is stacked and permuted by descending
+    caption length, `path` keeps the sample order (as in the reference)."""
+    imgs, caps, lens, paths = zip(*batch)
+    order = torch.sort(torch.tensor(lens), 0, True)
+    fields = {name: torch.stack([c[key] for c in caps]).squeeze()[order.indices]
+              for name, key in (("caption_ids", "input_ids"), ("token_type_ids", "token_type_ids"),
+                                ("attention_mask", "attention_mask"))}
+    fields["imgs"] = torch.stack(imgs)[order.indices]
+    fields["cap_lens"] = order.values
+    fields["path"] = list(paths)
+    return fields

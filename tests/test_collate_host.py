@@ -227,3 +227,17 @@ def test_call_with_sentence_instances_builds_sorted_labels(collate_fn, monkeypat
     want1, _ = _label_by_rendering((600, 500), boxes[0], [(16, 16)])
     assert np.array_equal(lab[0].numpy(), want0) and np.array_equal(lab[1].numpy(), want1)
     assert [next(iter(i.keys())) for i in batch["instances"]] == ["p1", "p0"]
+
+
+def test_multimodal_collate_sorts_by_caption_length():
+    from gloria.datasets.collate import multimodal_collate_fn
+    def sample(i, n):
+        ids = torch.zeros(1, 8, dtype=torch.int64); ids[0, :n] = i + 1
+        cap = {"input_ids": ids, "token_type_ids": torch.zeros(1, 8, dtype=torch.int64), "attention_mask": (ids > 0).long()}
+        return torch.full((3, 4, 4), float(i)), cap, n, f"path{i}"
+    out = multimodal_collate_fn([sample(0, 3), sample(1, 7), sample(2, 5)])
+    assert out["cap_lens"].tolist() == [7, 5, 3]
+    assert out["caption_ids"].shape == (3, 8) and out["caption_ids"][:, 0].tolist() == [2, 3, 1]
+    assert out["imgs"][:, 0, 0, 0].tolist() == [1.0, 2.0, 0.0]
+    assert out["attention_mask"].sum(1).tolist() == [7, 5, 3]
+    assert out["path"] == ["path0", "path1", "path2"]                      # not permuted (pretraining_dataset.py:279)
