@@ -102,3 +102,28 @@ def test_product_path_does_not_import_oracle():
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b|oracle[./]gloria_oracle|gen_golden", src, re.M), \
                     os.path.join(dirpath, f)
+
+
+def test_plan_invariants_on_random_caption_lengths():
+    """every word gets its own slot, sentences never straddle tiles unless they own them, work items cover every
+    tile exactly once - for many random batches (both tile capacities)"""
+    from gloria import _native as N
+    rng = np.random.default_rng(123)
+    for trial in range(40):
+        n = int(rng.integers(1, 300))
+        hi = [8, 40, 97, 257, 512][trial % 5]
+        lens = rng.integers(1, hi + 1, size=n).tolist()
+        for cap in (64, 32):
+            p = N.TilePlan(lens, "cpu", cap)
+            si, wi, slot = (t.numpy() for t in p.word_index("cpu"))
+            assert len(np.unique(slot)) == sum(lens) and slot.max() < p.n_slots and (slot % 64 < cap).all()
+            nsub, tf = p.tile_nsub.numpy(), p.tile_first.numpy()
+            covered = []
+            for t in p.pair_tile.numpy():
+                covered += [t, t + 1]
+            for t in p.single_tile.numpy():
+                covered += list(range(t, t + max(nsub[t], 1)))
+            assert sorted(covered) == list(range(p.n_tiles))
+            order = p.order.numpy()
+            seen = np.concatenate([order[tf[t]:tf[t + 1]] for t in range(p.n_tiles) if nsub[t] >= 0])
+            assert sorted(seen.tolist()) == list(range(n))                 # every sentence in exactly one tile (run)

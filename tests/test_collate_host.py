@@ -241,3 +241,17 @@ def test_multimodal_collate_sorts_by_caption_length():
     assert out["imgs"][:, 0, 0, 0].tolist() == [1.0, 2.0, 0.0]
     assert out["attention_mask"].sum(1).tolist() == [7, 5, 3]
     assert out["path"] == ["path0", "path1", "path2"]                      # not permuted (pretraining_dataset.py:279)
+
+
+def test_product_tap_tables_equal_the_oracle_over_many_sizes():
+    """the host copy of OpenCV's tap table (used for the box labels) and the oracle's agree entry by entry"""
+    from gloria.datasets.collate import _area_taps
+    rng = np.random.default_rng(21)
+    for _ in range(60):
+        ssize = int(rng.integers(257, 4200))
+        dsize = int(rng.integers(max(2, ssize // 40), min(ssize, 256) + 1))
+        scale = 1.0 / (float(dsize) / ssize)
+        idx, alpha = _area_taps(ssize, dsize, scale)
+        for d, taps in enumerate(co.area_tab(ssize, dsize, scale)):
+            assert [(int(idx[d, k]), alpha[d, k]) for k in range(len(taps))] == [(s, a) for s, a in taps]
+            assert (alpha[d, len(taps):] == 0).all()
