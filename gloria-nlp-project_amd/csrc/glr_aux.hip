@@ -13,11 +13,12 @@
 namespace {
 
 // ------------------------------------------------------------------ K5
+constexpr int K5_MAX_LAYERS = 16;     // BERT-base exposes 13 hidden states; `last_n_layers` may ask for all of them
 struct LayerPtrs {
-  const void* h[4];
+  const void* h[K5_MAX_LAYERS];
 };
 
-// grid (D/64, B), 256 threads = 64 features x 4 token phases.
+// grid (ceil(D/64), B), 256 threads = 64 features x 4 token phases; features past D are masked (any D).
 // dst[b][t] = word slot of token t (monotone non-decreasing over the kept tokens) or -1.
 __global__ void __launch_bounds__(256) k_segsum_fwd(LayerPtrs hp, int n_layers, int in_dtype,
                                                     const int* __restrict__ dst, float* __restrict__ word_emb,
@@ -30,7 +31,7 @@ __global__ void __launch_bounds__(256) k_segsum_fwd(LayerPtrs hp, int n_layers, 
   __syncthreads();
   // one thread per feature walks the tokens in order (fixed summation order => bitwise reproducible);
   // the other three quarter-blocks only help with zeroing and the transposed write-out
-  if (ph == 0) {
+  if (ph == 0 && d0 + dx < D) {
     for (int t = 0; t < L; ++t) {
       const int slot = dst[(size_t)b * L + t];
       if (slot < 0) continue;
@@ -43,9 +44,9 @@ __global__ void __launch_bounds__(256) k_segsum_fwd(LayerPtrs hp, int n_layers, 
   // word_emb [B, D, L]: rows of L floats per feature, written coalesced along L
   for (int i = threadIdx.x; i < 64 * L; i += 256) {
     const int dl = i / L, w = i % L;
-    word_emb[((size_t)b * D + d0 + dl) * L + w] = tile[dl * LP + w];
+    if (d0 + dl < D) word_emb[((size_t)b * D + d0 + dl) * L + w] = tile[dl * LP + w];
   }
-  if (threadIdx.x < 64) {                          // sentence embedding: mean over ALL L slots (text_model.py:110)
+  if (threadIdx.x < 64 && d0 + threadIdx.x < D) {                          // sentence embedding: mean over ALL L slots (text_model.py:110)
     float s = 0.f;
     for (int w = 0; w < L; ++w) s += tile[threadIdx.x * LP + w];
     sent_emb[(size_t)b * D + d0 + threadIdx.x] = s / (float)L;
@@ -62,9 +63,10 @@ __global__ void __launch_bounds__(256) k_segsum_bwd(const float* __restrict__ d_
   const int LP = L + 1;
   for (int i = threadIdx.x; i < 64 * L; i += 256) {
     const int dl = i / L, w = i % L;
-    tile[dl * LP + w] = d_word ? d_word[((size_t)b * D + d0 + dl) * L + w] : 0.f;
+    tile[dl * LP + w] = (d_word && d0 + dl < D) ? d_word[((size_t)b * D + d0 + dl) * L + w] : 0.f;
   }
   __syncthreads();
+  if (d0 + dx >= D) return;
   const float gs = d_sent ? d_sent[(size_t)b * D + d0 + dx] / (float)L : 0.f;
   for (int t = ph; t < L; t += 4) {
     const int slot = dst[(size_t)b * L + t];
@@ -338,15 +340,15 @@ extern "C" int glr_attn_reg_bwd(const float* amean, int B_img, int n_sent, int S
 extern "C" int glr_wordpiece_segsum_fwd(const void* const* hidden, int n_layers, int in_dtype, const int32_t* dst,
                                         float* word_emb, float* sent_emb, int B, int L, int D, int mean_layers,
                                         void* stream) {
-  if (!hidden || !dst || !word_emb || !sent_emb || n_layers < 1 || n_layers > 4 || B <= 0 || L <= 0 || D % 64 != 0)
+  if (!hidden || !dst || !word_emb || !sent_emb || n_layers < 1 || n_layers > K5_MAX_LAYERS || B <= 0 || L <= 0 || D <= 0)
     return GLR_EINVAL;
   if (in_dtype != GLR_F32 && in_dtype != GLR_BF16) return GLR_EDTYPE;
   LayerPtrs hp;
-  for (int l = 0; l < 4; ++l) hp.h[l] = l < n_layers ? hidden[l] : nullptr;
+  for (int l = 0; l < K5_MAX_LAYERS; ++l) hp.h[l] = l < n_layers ? hidden[l] : nullptr;
   for (int l = 0; l < n_layers; ++l) if (!hp.h[l]) return GLR_EINVAL;
   const size_t lds = (size_t)64 * (L + 1) * sizeof(float);
   if (lds > 64 * 1024) return GLR_EINVAL;
-  hipLaunchKernelGGL(k_segsum_fwd, dim3(D / 64, B), dim3(256), lds, (hipStream_t)stream, hp, n_layers, in_dtype, dst,
+  hipLaunchKernelGGL(k_segsum_fwd, dim3((D + 63) / 64, B), dim3(256), lds, (hipStream_t)stream, hp, n_layers, in_dtype, dst,
                      word_emb, sent_emb, L, D, mean_layers ? 1.f / (float)n_layers : 1.f);
   GLR_CHECK_LAUNCH();
   return GLR_OK;
@@ -355,11 +357,11 @@ extern "C" int glr_wordpiece_segsum_fwd(const void* const* hidden, int n_layers,
 extern "C" int glr_wordpiece_segsum_bwd(const float* d_word, const float* d_sent, const int32_t* dst, void* d_hidden,
                                         int out_dtype, int B, int L, int D, int n_layers, int mean_layers,
                                         void* stream) {
-  if (!dst || !d_hidden || B <= 0 || L <= 0 || D % 64 != 0 || n_layers < 1) return GLR_EINVAL;
+  if (!dst || !d_hidden || B <= 0 || L <= 0 || D <= 0 || n_layers < 1) return GLR_EINVAL;
   if (out_dtype != GLR_F32 && out_dtype != GLR_BF16) return GLR_EDTYPE;
   const size_t lds = (size_t)64 * (L + 1) * sizeof(float);
   if (lds > 64 * 1024) return GLR_EINVAL;
-  hipLaunchKernelGGL(k_segsum_bwd, dim3(D / 64, B), dim3(256), lds, (hipStream_t)stream, d_word, d_sent, dst, d_hidden,
+  hipLaunchKernelGGL(k_segsum_bwd, dim3((D + 63) / 64, B), dim3(256), lds, (hipStream_t)stream, d_word, d_sent, dst, d_hidden,
                      out_dtype, L, D, mean_layers ? 1.f / (float)n_layers : 1.f);
   GLR_CHECK_LAUNCH();
   return GLR_OK;

@@ -28,12 +28,30 @@ def build_gloria_model(cfg):
     return models.gloria_model.GLoRIA(cfg)
 
 
-def build_gloria_from_ckpt(ckpt):
-    """Reference checkpoint layout: {"state_dict": {"gloria.<...>": tensor}, "hyper_parameters": cfg}."""
+def clean_state_dict(state_dict):
+    """Keys a REFERENCE checkpoint carries that this build does not register as state:
+    `*.embeddings.position_ids` - transformers==4.2.1 (requirements.txt:83) keeps BertEmbeddings.position_ids as a
+    persistent buffer, so every reference checkpoint holds `gloria.text_encoder.model.embeddings.position_ids`;
+    it is the constant arange(512) and is rebuilt here as a non-persistent buffer."""
+    return {k: v for k, v in state_dict.items() if not k.endswith("embeddings.position_ids")}
+
+
+def build_gloria_from_ckpt(ckpt, cfg=None):
+    """Reference checkpoint layout: {"state_dict": {"gloria.<...>": tensor}, "hyper_parameters": cfg}
+    (/root/reference/gloria/builder.py:35-50).  The file is read with the weights-only loader (nothing in it is
+    executed); `hyper_parameters` written by the reference are OmegaConf objects, which that loader refuses - pass
+    `cfg` (the YAML the run was started from) for such files."""
     from .config import Config
-    ckpt = torch.load(ckpt, map_location="cpu", weights_only=True)
-    cfg = Config(ckpt["hyper_parameters"])
-    fixed = {k.split("gloria.")[-1]: v for k, v in ckpt["state_dict"].items()}
+    try:
+        ckpt = torch.load(ckpt, map_location="cpu", weights_only=True)
+    except Exception as e:              # noqa: BLE001 - the unpickler's own error types vary between torch versions
+        raise RuntimeError(
+            f"{ckpt}: the weights-only loader refused this checkpoint ({type(e).__name__}: {e}). Reference checkpoints "
+            "pickle their OmegaConf hyper_parameters; re-save the file with only 'state_dict' (and plain-dict "
+            "hyper_parameters) in the environment that wrote it - it is never unpickled here") from e
+    if cfg is None:
+        cfg = Config(ckpt["hyper_parameters"])
+    fixed = {k.split("gloria.")[-1]: v for k, v in clean_state_dict(ckpt["state_dict"]).items()}
     gloria_model = build_gloria_model(cfg)
     gloria_model.load_state_dict(fixed)
     return gloria_model

@@ -71,6 +71,17 @@ class DistContext:
         dist.all_gather_into_tensor(out, t, group=self.group)
         return out.cpu().tolist()
 
+    def all_reduce_scalar(self, value, like=None):
+        """SUM of a scalar (tensor or Python number) over the group, returned on the caller's device."""
+        if torch.is_tensor(value):
+            t = value.detach().float().reshape(1).clone()
+        else:
+            dev = like.device if torch.is_tensor(like) else (
+                torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(self.group) == "nccl" else "cpu")
+            t = torch.full((1,), float(value), dtype=torch.float32, device=dev)
+        dist.all_reduce(t, group=self.group)
+        return t[0]
+
     # -- parameter gradients
     def allreduce_grads(self, params, bucket_bytes=64 << 20):
         """SUM all-reduce of .grad over the group in flat buckets; returns after all buckets landed."""
@@ -114,6 +125,8 @@ class GradReducer:
     def __init__(self, params, ctx, bucket_bytes=64 << 20):
         self.ctx = ctx
         self.buckets = []                 # (flat tensor, [params])
+        self._views = {}                  # param -> its gradient view into the bucket
+        self._fired = set()               # params whose gradient arrived in the current backward
         cur, size = [], 0
         for p in reversed([p for p in params if p.requires_grad]):
             cur.append(p)
@@ -125,6 +138,7 @@ class GradReducer:
             self._seal(cur)
         self._pending = []
         self._ready = [0] * len(self.buckets)
+        self._open = False                # a zero_grad() .. finish() cycle is in progress
 
     def _seal(self, plist):
         dev, dt = plist[0].device, plist[0].dtype
@@ -135,19 +149,29 @@ class GradReducer:
             # the view gets the parameter's own strides (channels-last conv weights, incl. the ambiguous 1x1 case):
             # fused Adam requires params and grads with identical strides, and autograd's layout contract
             # then accumulates in place without a copy.  Parameters are dense, so n elements cover the view.
-            p.grad = flat.as_strided(p.shape, p.stride(), storage_offset=off)
-            assert p.grad.stride() == p.stride() and p.grad.numel() == n
+            view = flat.as_strided(p.shape, p.stride(), storage_offset=off)
+            assert view.stride() == p.stride() and view.numel() == n
+            self._views[p] = view
+            p.grad = view
             off += n
-            p.register_post_accumulate_grad_hook(lambda _p, i=idx: self._on_ready(i))
+            p.register_post_accumulate_grad_hook(lambda _p, i=idx: self._on_ready(i, _p))
         self.buckets.append((flat, plist))
 
     def zero_grad(self):
-        for flat, _ in self.buckets:
+        for flat, plist in self.buckets:
             flat.zero_()
+            for p in plist:
+                p.grad = self._views[p]           # re-attach: finish() hides the views of unused parameters
         self._ready = [0] * len(self.buckets)
         self._pending = []
+        self._fired = set()
+        self._open = True
 
-    def _on_ready(self, i):
+    def _on_ready(self, i, p):
+        if not self._open or p in self._fired:
+            # a bucket may only be reduced once per cycle: a second backward would all-reduce already reduced sums
+            raise RuntimeError("GradReducer: one backward per zero_grad()/finish() cycle (no gradient accumulation)")
+        self._fired.add(p)
         self._ready[i] += 1
         if self._ready[i] == len(self.buckets[i][1]):
             self._pending.append(dist.all_reduce(self.buckets[i][0], group=self.ctx.group, async_op=True))
@@ -160,6 +184,13 @@ class GradReducer:
         for w in self._pending:
             w.wait()
         self._pending = []
+        self._open = False
+        # a parameter no rank used (e.g. the BERT pooler with last_n_layers > 1) must look to the optimizer as it
+        # does in the single-process run - grad None, skipped - not as a zero gradient that weight decay acts on
+        for _, plist in self.buckets:
+            for p in plist:
+                if p not in self._fired:
+                    p.grad = None
 
 
 def init_from_env(backend=None):

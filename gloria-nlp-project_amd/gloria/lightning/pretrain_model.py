@@ -75,5 +75,5 @@ class PretrainModel(nn.Module):
             from ..config import Config
             cfg = Config(ckpt["hyper_parameters"])
         module = cls(cfg)
-        module.load_state_dict(ckpt["state_dict"])
+        module.load_state_dict(builder.clean_state_dict(ckpt["state_dict"]))
         return module

@@ -139,14 +139,16 @@ class GLoRIA(nn.Module):
         return self.global_loss(img_emb_g, text_emb_g, temp3=self.temp3)
 
     def calc_loss(self, img_emb_l, img_emb_g, text_emb_l, text_emb_g, sents, segmentation_labels=None):
-        loss_ = 0
+        # `shared`: terms every data-parallel rank evaluates on the GLOBAL batch (identical on all ranks);
+        # `share`: terms of which a rank holds only its images' share (the shares of all ranks add up)
+        shared, share = 0, 0
         l_loss0, l_loss1, no_attn_loss, kl_loss, entropy_loss, attn_maps = self._calc_local_loss(
             img_emb_l, text_emb_l, sents)
         if self.local_loss_weight != 0:
-            loss_ = loss_ + (l_loss0 + l_loss1) * self.local_loss_weight
+            shared = shared + (l_loss0 + l_loss1) * self.local_loss_weight
         if self.global_loss_weight != 0:
             g_loss0, g_loss1 = self._calc_global_loss(img_emb_g, text_emb_g)
-            loss_ = loss_ + (g_loss0 + g_loss1) * self.global_loss_weight
+            shared = shared + (g_loss0 + g_loss1) * self.global_loss_weight
         if segmentation_labels is not None and self.segmentation_loss_weight:
             # attention-supervision term (ref :143-147)
             if getattr(attn_maps, "flat", None) is not None and attn_maps.flat.is_cuda:
@@ -158,9 +160,22 @@ class GLoRIA(nn.Module):
                 seg = -torch.log((segmentation_labels * up).sum(-1).sum(-1)).mean()
             if self.dist is not None and self.dist.active:
                 seg = seg / self.dist.world_size          # mean over the global batch
-            loss_ = loss_ + seg * self.segmentation_loss_weight
-        loss_ = loss_ + no_attn_loss + kl_loss + entropy_loss
+            share = share + seg * self.segmentation_loss_weight
+        share = share + no_attn_loss + kl_loss + entropy_loss
+        loss_ = shared + share
+        self._loss_parts = (shared.detach() if torch.is_tensor(shared) else shared,
+                            share.detach() if torch.is_tensor(share) else share)
         return loss_, attn_maps
+
+    def global_batch_loss(self):
+        """The value of the last calc_loss over the GLOBAL batch, identical on every data-parallel rank:
+        the global-batch terms once plus the SUM over ranks of the per-rank shares (segmentation and regulariser
+        terms).  Single process: the loss itself.  One small collective, used for logging, validation and the
+        plateau scheduler - the value a rank differentiates stays its own (gradients are SUM-reduced)."""
+        shared, share = self._loss_parts
+        if self.dist is not None and self.dist.active:
+            share = self.dist.all_reduce_scalar(share, like=shared)
+        return shared + share
 
     def forward(self, x):
         img_emb_l, img_emb_g = self.image_encoder_forward(x["imgs"])

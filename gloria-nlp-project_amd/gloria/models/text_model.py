@@ -225,8 +225,10 @@ class BertEncoder(nn.Module):
             if self.aggregate_method not in ("sum", "mean"):
                 print(self.aggregate_method)
                 raise Exception("Aggregation method not implemented")
-            if self.agg_tokens and layers[0].is_cuda and self.last_n_layers <= 4 and layers[0].shape[2] % 64 == 0:
-                # K5: segment-sum fused with the layer reduction and the L-mean, [B, D, L] written directly
+            if self.agg_tokens and layers[0].is_cuda:
+                # K5 (every GPU call, any D / layer count): segment-sum fused with the layer reduction and the
+                # L-mean, [B, D, L] written directly.  The torch branch below only ever sees CPU tensors (host-logic
+                # tests and the CPU baseline of bench.py).
                 host = host_ids(ids)
                 B, L = host.shape
                 dst, starts, n_words = wordpiece_slots(host, self.vocab)

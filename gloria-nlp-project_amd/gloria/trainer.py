@@ -83,6 +83,13 @@ class Trainer:
             torch.nn.utils.clip_grad_norm_(self.params, self.clip)
         self.optimizer.step()
         self.global_step += 1
+        return self._global_loss(model, loss)
+
+    def _global_loss(self, model, loss):
+        """what a single process would report: under data parallelism a rank's own loss holds only its share of
+        the segmentation / regulariser terms (GLoRIA.global_batch_loss adds the other ranks' shares)"""
+        if self.dist is not None and self.dist.active and hasattr(model.gloria, "global_batch_loss"):
+            return model.gloria.global_batch_loss().detach()
         return loss.detach()
 
     @torch.no_grad()
@@ -94,7 +101,7 @@ class Trainer:
             ctx = torch.autocast(self.device.type, dtype=self.autocast_dtype) if self.autocast_dtype else _Null()
             with ctx:
                 out = (model.validation_step if split == "val" else model.test_step)(batch, i)
-            tot += float(out["loss"])
+            tot += float(self._global_loss(model, out["loss"]))      # identical on every rank
             n += 1
         model.train()
         return tot / max(n, 1)
@@ -139,8 +146,9 @@ class Trainer:
         torch.save(ckpt, path)
 
     def resume(self, model, path):
+        from .builder import clean_state_dict
         ckpt = torch.load(path, map_location="cpu", weights_only=True)
-        model.load_state_dict(ckpt["state_dict"])
+        model.load_state_dict(clean_state_dict(ckpt["state_dict"]))
         if self.optimizer is not None and "optimizer_states" in ckpt:
             self.optimizer.load_state_dict(ckpt["optimizer_states"][0])
         self.global_step = ckpt.get("global_step", 0)

@@ -223,7 +223,7 @@ int glr_global_sim_bwd(const float* img, const float* txt, const float* ni, cons
  * K5  word-piece -> word aggregation (segment sum) fused with the reduction over the last BERT layers
  * and the mean over the L word slots.  Replaces BertEncoder.aggregate_tokens + the post-processing of
  * BertEncoder.forward (gloria/models/text_model.py:32-90, 96-131).
- *   hidden[n_layers]  device pointers to [B, L, D] hidden states (in_dtype), n_layers <= 4
+ *   hidden[n_layers]  device pointers to [B, L, D] hidden states (in_dtype), n_layers <= 16, any D
  *   dst [B, L] int32  word slot of every token (-1 = dropped), computed on the host from the ids
  *   word_emb [B, D, L] fp32 (the layout local_loss takes), sent_emb [B, D] fp32
  *   mean_layers       0: sum over layers (aggregate_method 'sum'), 1: mean

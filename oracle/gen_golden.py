@@ -62,6 +62,23 @@ def gen_attention(ref, out):
         print("attention", name, tuple(wc.shape), tuple(attn.shape))
 
 
+def gen_attention_grads(ref, out):
+    """attention_fn OUTPUT gradients (G1 with grads): d/d(query, context, no_attn_vec) of
+    sum(weightedContext * gw) + sum(attn * ga) by the reference's own autograd."""
+    for name in gi.ATTN_CASES:
+        q, ctx, temp1, na = gi.attn_inputs(name)
+        tq, tc = t(q, True), t(ctx, True)
+        tna = None if na is None else t(na, True)
+        wc, attn = ref.attention_fn(tq, tc, temp1, no_attn_vec=tna)
+        gw, ga = gi.attn_upstream(name, tuple(wc.shape), tuple(attn.shape))
+        ((wc * t(gw)).sum() + (attn * t(ga)).sum()).backward()
+        pack(out, f"attn_grad/{name}/grad_query", tq.grad)
+        pack(out, f"attn_grad/{name}/grad_context", tc.grad)
+        if tna is not None:
+            pack(out, f"attn_grad/{name}/grad_no_attn", tna.grad)
+        print("attention grads", name, float(tq.grad.abs().max()), float(tc.grad.abs().max()))
+
+
 def ref_sim_matrix(ref, img, words, cap_lens, no_attn, temp1=4.0, temp2=5.0, temp3=10.0, agg="sum"):
     """B x B similarity matrix assembled from the reference's own attention_fn and
     cosine_similarity, sentence by sentence (the reference's local_loss does not return it)."""
@@ -152,9 +169,46 @@ def gen_text(out):
     print("text", tuple(word.shape), tuple(sent.shape))
 
 
+def _ref_text_encoder(tm, hidden, vocab, grad=False):
+    enc = tm.BertEncoder.__new__(tm.BertEncoder)
+    torch.nn.Module.__init__(enc)
+    enc.last_n_layers, enc.aggregate_method, enc.norm = 4, "sum", False
+    enc.embedding_dim, enc.agg_tokens = hidden[0].shape[-1], True
+    enc.emb_local = enc.emb_global = None
+    enc.idxtoword = vocab
+    hs = tuple(t(h, grad) for h in hidden)
+    enc.model = lambda i, m, tt: (None, None, hs)
+    return enc, hs
+
+
+def gen_text_wide(out):
+    """word-piece aggregation of the real BertEncoder.forward at D = 64 (all outputs + gradients of the four
+    hidden states used) and D = 768 (sub-sampled outputs): the widths of the HIP kernel's tile and of BERT-base."""
+    tm = load_ref("ref_text_model", "gloria/models/text_model.py")
+    for D in (64, 768):
+        ids, hidden, vocab = gi.text_inputs(D=D)
+        enc, hs = _ref_text_encoder(tm, hidden, vocab, grad=(D == 64))
+        if D == 64:
+            word, sent, sents = enc.forward(t(ids), None, None)
+            gw, gs = gi.normal(9, *word.shape), gi.normal(10, *sent.shape)
+            ((word * t(gw)).sum() + (sent * t(gs)).sum()).backward()
+            out["text64/word_emb"] = word.detach().numpy().astype(np.float32)
+            out["text64/sent_emb"] = sent.detach().numpy().astype(np.float32)
+            for k in range(1, 5):
+                out[f"text64/grad_hidden_m{k}"] = hs[-k].grad.numpy().astype(np.float32)
+            assert hs[0].grad is None          # only the last four layers take part
+        else:
+            with torch.no_grad():
+                word, sent, sents = enc.forward(t(ids), None, None)
+            pack(out, "text768/word_emb", word)
+            out["text768/sent_emb"] = sent.numpy().astype(np.float32)
+        print("text wide", D, tuple(word.shape), tuple(sent.shape))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-b256", action="store_true")
+    ap.add_argument("--only", default=None, help="comma-separated fixture files to (re)generate, e.g. attention_grad,text_wide")
     args = ap.parse_args()
     torch.manual_seed(0)
     ref = load_ref("ref_gloria_loss", "gloria/loss/gloria_loss.py")
@@ -163,7 +217,11 @@ def main():
                       ("local.npz", lambda o: gen_local(ref, o)),
                       ("global.npz", lambda o: gen_global(ref, o)),
                       ("text.npz", gen_text),
+                      ("attention_grad.npz", lambda o: gen_attention_grads(ref, o)),
+                      ("text_wide.npz", gen_text_wide),
                       ("sim.npz", lambda o: gen_sim(ref, o, args.skip_b256))):
+        if args.only is not None and fname[:-4] not in args.only.split(","):
+            continue
         out = {}
         fn(out)
         np.savez_compressed(os.path.join(OUT, fname), **out)

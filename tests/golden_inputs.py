@@ -101,6 +101,12 @@ def attn_inputs(name):
     return query, ctx, temp1, no_attn
 
 
+def attn_upstream(name, wc_shape, map_shape):
+    """upstream gradients of attention_fn's two outputs for the attention_grad fixtures"""
+    seed = case_seed(name)
+    return normal(seed + 10, *wc_shape), normal(seed + 11, *map_shape)
+
+
 def global_inputs(name):
     B, D, zero_row = GLOBAL_CASES[name]
     seed = case_seed(name)

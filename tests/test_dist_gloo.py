@@ -36,6 +36,13 @@ def _inputs():
     return img, words, ig, tg
 
 
+def _seg_labels():
+    rng = np.random.default_rng(21)
+    lab = torch.from_numpy(rng.random((B, 12, 12)) < 0.3)
+    lab[:, 0, 0] = True                   # never empty
+    return lab
+
+
 def _patch_with_oracle():
     """CPU stand-ins with the product functions' signatures, built on the oracle."""
     from gloria.loss import gloria_loss as GL
@@ -138,7 +145,37 @@ def _worker(rank, port, out):
         x = torch.full((2, 6), float(rank + 1))
         lin(x).sum().backward()
         red.finish()
-        rgrads = [p.grad.clone() for p in plist]
+        rgrads = [None if p.grad is None else p.grad.clone() for p in plist]
+        # a parameter nobody used is skipped by the optimizer exactly as in a single process (no weight decay on it)
+        opt = torch.optim.Adam(plist, lr=0.1, weight_decay=1e-2)
+        opt.step()
+        unused_after = unused.detach().clone()
+        # the next cycle re-attaches the bucket views; a second backward inside one cycle is refused
+        red.zero_grad()
+        assert all(p.grad is not None for p in plist)
+        lin(x).sum().backward()
+        double = False
+        try:
+            lin(x).sum().backward()
+        except RuntimeError as e:
+            double = "one backward per" in str(e)
+        red.finish()
+        # attention-finetune configuration (imagenome_attn_finetune_config.yaml:51-53): contrastive weights 0,
+        # segmentation weight 1 -> a rank's own loss is only its SHARE; global_batch_loss() is the full value
+        gf = _bare_gloria(dctx)
+        gf.local_loss_weight = gf.global_loss_weight = 0
+        gf.segmentation_loss_weight = 1.0
+        labels = _seg_labels()[sl]
+        fl, _ = gf.calc_loss(img[sl].clone(), ig[sl].clone(), words[sl].clone(), tg[sl].clone(), Sents(), labels)
+        val = float(gf.global_batch_loss())
+        sch_opt = torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], lr=1.0)
+        sch = torch.optim.lr_scheduler.ReduceLROnPlateau(sch_opt, factor=0.5, patience=0)
+        sch.step(1.0)
+        sch.step(val + 1.0)            # worse than the best value on every rank alike -> the LR halves everywhere
+        fin = {"own": float(fl), "val": val, "lr": sch_opt.param_groups[0]["lr"]}
+        g2 = _bare_gloria(dctx)
+        l2, _ = g2.calc_loss(li.detach(), lig.detach(), lw.detach(), ltg.detach(), Sents())
+        fin["plain_val"] = float(g2.global_batch_loss())
         # same step with the no-attention vector and the three attention regularisers switched on
         ga = _bare_gloria(dctx, aux=True)
         ai, aw = img[sl].clone().requires_grad_(True), words[sl].clone().requires_grad_(True)
@@ -147,7 +184,8 @@ def _worker(rank, port, out):
         aux = {"l": [float(l0), float(l1)], "shares": [float(na), float(kl), float(ent)], "gi": ai.grad, "gw": aw.grad,
                "gna": ga.no_attn_vec.grad}
         torch.save({"loss": loss.detach(), "gi": li.grad, "gw": lw.grad, "gig": lig.grad, "gtg": ltg.grad, "aux": aux,
-                    "maps": [m.detach() for m in maps], "p0": p[0].grad, "p1": p[1].grad, "ints": ints, "rgrads": rgrads},
+                    "maps": [m.detach() for m in maps], "p0": p[0].grad, "p1": p[1].grad, "ints": ints, "rgrads": rgrads,
+                    "unused_after": unused_after, "double": double, "fin": fin},
                    os.path.join(out, f"r{rank}.pt"))
     finally:
         dist.destroy_process_group()
@@ -205,4 +243,17 @@ def test_sharded_loss_equals_full_batch(tmp_path):
     for r in range(WORLD):
         for a, b in zip(res[r]["rgrads"][:-1], want):
             np.testing.assert_allclose(a.numpy(), b.numpy(), rtol=1e-5, atol=1e-6)
-        assert torch.equal(res[r]["rgrads"][-1], torch.zeros(4))
+        assert res[r]["rgrads"][-1] is None                       # unused parameter: hidden from the optimizer
+        assert torch.equal(res[r]["unused_after"], torch.ones(4))  # ... so weight decay did not move it
+        assert res[r]["double"], "a second backward inside one reducer cycle must raise"
+    # attention-finetune configuration: validation value and plateau LR identical on every rank and equal to the
+    # single-process loss (the rank's own loss is only its share)
+    maps = orc.local_loss(img, words, CAP)[5]
+    seg_full = float(orc.attention_supervision_loss(maps, _seg_labels(), 1.0))
+    for r in range(WORLD):
+        f = res[r]["fin"]
+        np.testing.assert_allclose(f["val"], seg_full, rtol=1e-5)
+        assert f["val"] == res[0]["fin"]["val"] and f["lr"] == res[0]["fin"]["lr"] == 0.5
+        assert abs(f["own"] - seg_full) > 1e-3 * abs(seg_full)     # the un-reduced value differs: this was the bug
+        np.testing.assert_allclose(f["plain_val"], float(full), rtol=1e-5)
+    np.testing.assert_allclose(sum(res[r]["fin"]["own"] for r in range(WORLD)), seg_full, rtol=1e-5)

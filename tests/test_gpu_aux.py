@@ -31,42 +31,73 @@ def test_cosine_matches_oracle_with_grads():
     assert torch.isfinite(a.grad).all()
 
 
-def test_wordpiece_segsum_matches_reference(golden):
+def _k5(ids, hidden, vocab, grad=False):
+    """K5 through the C ABI: token -> slot indices from the host ids, last four hidden states on the GPU"""
     from gloria.models import text_model as tm
-    g = golden("text")
-    ids, hidden, vocab = gi.text_inputs(D=64)      # kernel needs D % 64 == 0: separate golden below
     v = tm.Vocab.from_dict(vocab)
     dst, starts, n_words = tm.wordpiece_slots(ids, v)
-    layers = [torch.from_numpy(h).to(DEV).requires_grad_(True) for h in hidden[-4:]]
+    layers = [torch.from_numpy(h).to(DEV).requires_grad_(grad) for h in hidden[-4:]]
     dst_d = torch.from_numpy(dst.astype(np.int32)).to(DEV)
     word, sent = tm.WordpieceSegSumFn.apply(dst_d, False, *layers)
-    # torch restatement (validated against the reference's outputs in tests/test_host_logic.py)
-    enc = tm.BertEncoder.__new__(tm.BertEncoder)
-    torch.nn.Module.__init__(enc)
-    enc.vocab = v
-    cl = [torch.from_numpy(h).requires_grad_(True) for h in hidden[-4:]]
-    ref_words, _ = enc.aggregate_tokens(torch.stack(cl).sum(0), torch.from_numpy(ids))
-    np.testing.assert_allclose(word.detach().cpu().numpy(), ref_words.permute(0, 2, 1).detach().numpy(), rtol=1e-6, atol=1e-6)
-    np.testing.assert_allclose(sent.detach().cpu().numpy(), ref_words.mean(1).detach().numpy(), rtol=1e-5, atol=1e-6)
-    gw = torch.from_numpy(gi.normal(9, *word.shape))
-    gs = torch.from_numpy(gi.normal(10, *sent.shape))
-    ((word * gw.to(DEV)).sum() + (sent * gs.to(DEV)).sum()).backward()
-    ((ref_words.permute(0, 2, 1) * gw).sum() + (ref_words.mean(1) * gs).sum()).backward()
-    for a, b in zip(layers, cl):
-        np.testing.assert_allclose(a.grad.cpu().numpy(), b.grad.numpy(), rtol=1e-5, atol=1e-6)
+    return word, sent, layers
 
 
-def test_wordpiece_segsum_golden_shape(golden):
-    """the exact fixture of the reference run (D = 48) through the encoder's torch path on the GPU"""
+def test_wordpiece_segsum_golden_d64_with_grads(golden):
+    """K5 DIRECTLY against the reference's BertEncoder.forward (tests/golden/text_wide.npz, D = 64): outputs
+    and the gradients of the four hidden states"""
+    g = golden("text_wide")
+    ids, hidden, vocab = gi.text_inputs(D=64)
+    word, sent, layers = _k5(ids, hidden, vocab, grad=True)
+    np.testing.assert_allclose(word.detach().cpu().numpy(), g["text64/word_emb"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(sent.detach().cpu().numpy(), g["text64/sent_emb"], rtol=1e-5, atol=1e-6)
+    gw = torch.from_numpy(gi.normal(9, *word.shape)).to(DEV)
+    gs = torch.from_numpy(gi.normal(10, *sent.shape)).to(DEV)
+    ((word * gw).sum() + (sent * gs).sum()).backward()
+    for k in range(1, 5):
+        np.testing.assert_allclose(layers[-k].grad.cpu().numpy(), g[f"text64/grad_hidden_m{k}"], rtol=1e-5, atol=1e-6)
+
+
+def test_wordpiece_segsum_golden_d768_and_d48(golden):
+    """K5 against the reference at BERT-base width (sub-sampled fixture) and at the original D = 48 fixture
+    (a width that is not a multiple of the kernel's 64-feature tile)"""
+    g = golden("text_wide")
+    ids, hidden, vocab = gi.text_inputs(D=768)
+    word, sent, _ = _k5(ids, hidden, vocab)
+    w = word.cpu().numpy()
+    assert tuple(g["text768/word_emb.shape"]) == w.shape
+    np.testing.assert_allclose(gi.subsample(w), g["text768/word_emb.sample"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(sent.cpu().numpy(), g["text768/sent_emb"], rtol=1e-5, atol=1e-6)
+    g48 = golden("text")
+    ids, hidden, vocab = gi.text_inputs()
+    word, sent, _ = _k5(ids, hidden, vocab)
+    np.testing.assert_allclose(word.cpu().numpy(), g48["text/word_emb"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(sent.cpu().numpy(), g48["text/sent_emb"], rtol=1e-5, atol=1e-6)
+
+
+def test_text_encoder_gpu_always_takes_k5(golden):
+    """BertEncoder.forward on GPU tensors has ONE aggregation path (K5), whatever the width: the encoder's own
+    post-processing on the D = 48 fixture equals the reference's outputs"""
     from gloria.models import text_model as tm
-    g = golden("text")
+    g48 = golden("text")
     ids, hidden, vocab = gi.text_inputs()
     enc = tm.BertEncoder.__new__(tm.BertEncoder)
     torch.nn.Module.__init__(enc)
     enc.vocab = tm.Vocab.from_dict(vocab)
-    summed = torch.stack([torch.from_numpy(h).to(DEV) for h in hidden[-4:]]).sum(0)
-    words, sents = enc.aggregate_tokens(summed, torch.from_numpy(ids))
-    np.testing.assert_allclose(words.permute(0, 2, 1).cpu().numpy(), g["text/word_emb"], rtol=1e-5, atol=1e-5)
+    enc.last_n_layers, enc.aggregate_method, enc.norm, enc.agg_tokens = 4, "sum", False, True
+    enc.embedding_dim, enc.emb_local, enc.emb_global = 48, None, None
+    hs = tuple(torch.from_numpy(h).to(DEV) for h in hidden)
+    enc.model = lambda i, m, tt: (None, None, hs)
+    calls = []
+    orig = tm.WordpieceSegSumFn.apply
+    tm.WordpieceSegSumFn.apply = lambda *a: (calls.append(1), orig(*a))[1]
+    try:
+        word, sent, sents = enc.forward(torch.from_numpy(ids).to(DEV), None, None)
+    finally:
+        tm.WordpieceSegSumFn.apply = orig
+    assert calls, "the GPU call did not go through K5"
+    np.testing.assert_allclose(word.cpu().numpy(), g48["text/word_emb"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(sent.cpu().numpy(), g48["text/sent_emb"], rtol=1e-5, atol=1e-6)
+    assert ["\t".join(s) for s in sents] == list(g48["text/sents"])
 
 
 def test_attention_supervision_matches_oracle():

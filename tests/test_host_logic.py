@@ -109,3 +109,57 @@ def test_loss_refuses_cpu_tensors():
         GL.local_loss(torch.zeros(2, 64, 3, 3), torch.zeros(2, 64, 5), [2, 2])
     with pytest.raises(RuntimeError):
         GL.local_loss(torch.zeros(2, 64, 3, 3), torch.zeros(2, 64, 5), [2, 2], no_attn_loss_weight=1.0)
+
+
+def test_reference_shaped_checkpoint_loads_and_resumes(tmp_path):
+    """A checkpoint as the REFERENCE writes it (builder.py:35-50): `gloria.*` keys, BatchNorm
+    `num_batches_tracked`, and transformers==4.2.1's persistent `embeddings.position_ids` buffer - through
+    build_gloria_from_ckpt, load_from_checkpoint(cfg=cfg) and Trainer.save_checkpoint -> resume (weights-only
+    loader): parameters, optimizer state and global_step survive."""
+    from gloria import builder
+    from gloria.trainer import Trainer
+    cfg = tiny_cfg()
+    dm = builder.build_data_module(cfg)
+    model = builder.build_lightning_model(cfg, dm)
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    assert "gloria.img_encoder.model.bn1.num_batches_tracked" in sd
+    sd["gloria.text_encoder.model.embeddings.position_ids"] = torch.arange(512).unsqueeze(0)
+    path = tmp_path / "ref_like.ckpt"
+    torch.save({"state_dict": sd, "hyper_parameters": cfg.to_dict(), "epoch": 3, "global_step": 77}, path)
+    g = builder.build_gloria_from_ckpt(str(path))
+    for k, v in g.state_dict().items():
+        assert torch.equal(v, sd["gloria." + k]), k
+    again = builder.build_lightning_model(cfg, dm, ckpt=str(path))
+    assert all(torch.equal(v, sd[k]) for k, v in again.state_dict().items())
+
+    # resume: one optimisation step on a stand-in loss, save, load into a fresh trainer + model
+    tr = Trainer(cfg, device="cpu", precision=32)
+    tr.setup(model)
+    loss = sum((p.float() ** 2).sum() for p in list(model.parameters())[:6])
+    loss.backward()
+    tr.optimizer.step()
+    tr.global_step, model.current_epoch = 5, 2
+    ck = tmp_path / "last.ckpt"
+    tr.save_checkpoint(model, str(ck))
+    m2 = builder.build_lightning_model(cfg, dm)
+    tr2 = Trainer(cfg, device="cpu", precision=32)
+    tr2.setup(m2)
+    tr2.resume(m2, str(ck))
+    assert tr2.global_step == 5 and m2.current_epoch == 2
+    for (k1, v1), (k2, v2) in zip(model.state_dict().items(), m2.state_dict().items()):
+        assert k1 == k2 and torch.equal(v1, v2), k1
+    s1, s2 = tr.optimizer.state_dict()["state"], tr2.optimizer.state_dict()["state"]
+    assert s1.keys() == s2.keys() and len(s1) > 0
+    for k in s1:
+        assert torch.equal(s1[k]["exp_avg"], s2[k]["exp_avg"]) and torch.equal(s1[k]["exp_avg_sq"], s2[k]["exp_avg_sq"])
+
+
+def test_unloadable_hyper_parameters_are_reported(tmp_path):
+    """hyper_parameters pickled as arbitrary objects (the reference stores OmegaConf) are refused by the
+    weights-only loader: the error says what to do, nothing from the file is executed"""
+    from gloria import builder
+    import fractions
+    path = tmp_path / "omegaconf_like.ckpt"
+    torch.save({"state_dict": {}, "hyper_parameters": fractions.Fraction(1, 3)}, path)   # any non-allow-listed class
+    with pytest.raises(RuntimeError, match="weights-only loader refused"):
+        builder.build_gloria_from_ckpt(str(path))

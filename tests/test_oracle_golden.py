@@ -37,6 +37,22 @@ def test_attention_fn(golden, name):
     check(g, f"attn/{name}/map", attn)
 
 
+@pytest.mark.parametrize("name", list(gi.ATTN_CASES))
+def test_attention_fn_output_grads(golden, name):
+    """gradients of attention_fn's OWN outputs (weighted context and maps) by the reference's autograd"""
+    g = golden("attention_grad")
+    q, ctx, temp1, na = gi.attn_inputs(name)
+    tq, tc = t(q, True), t(ctx, True)
+    tna = None if na is None else t(na, True)
+    wc, attn = orc.attention_fn(tq, tc, temp1, no_attn_vec=tna)
+    gw, ga = gi.attn_upstream(name, tuple(wc.shape), tuple(attn.shape))
+    ((wc * t(gw)).sum() + (attn * t(ga)).sum()).backward()
+    check(g, f"attn_grad/{name}/grad_query", tq.grad, rtol=2e-4, atol=2e-6)
+    check(g, f"attn_grad/{name}/grad_context", tc.grad, rtol=2e-4, atol=2e-6)
+    if tna is not None:
+        check(g, f"attn_grad/{name}/grad_no_attn", tna.grad, rtol=2e-4, atol=2e-5)
+
+
 @pytest.mark.parametrize("name", list(gi.LOCAL_CASES))
 def test_local_loss_and_grads(golden, name):
     g = golden("local")
@@ -118,6 +134,24 @@ def test_text_postprocess(golden):
     # cap_lens rule (gloria_model.py:107-109): bracket tokens are not counted, +1
     lens = orc.cap_lens_from_sents(sents)
     assert lens == [sum(1 for w in s if not w.startswith("[")) + 1 for s in sents]
+
+
+def test_text_postprocess_wide(golden):
+    """the same post-processing at the widths of the HIP kernel's tile (64) and of BERT-base (768)"""
+    g = golden("text_wide")
+    ids, hidden, vocab = gi.text_inputs(D=64)
+    hs = [t(h, True) for h in hidden]
+    word, sent, _ = orc.text_postprocess(hs, t(ids), vocab)
+    np.testing.assert_allclose(word.detach().numpy(), g["text64/word_emb"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(sent.detach().numpy(), g["text64/sent_emb"], rtol=1e-5, atol=1e-6)
+    gw, gs = gi.normal(9, *word.shape), gi.normal(10, *sent.shape)
+    ((word * t(gw)).sum() + (sent * t(gs)).sum()).backward()
+    for k in range(1, 5):
+        np.testing.assert_allclose(hs[-k].grad.numpy(), g[f"text64/grad_hidden_m{k}"], rtol=1e-5, atol=1e-6)
+    ids, hidden, vocab = gi.text_inputs(D=768)
+    word, sent, _ = orc.text_postprocess([t(h) for h in hidden], t(ids), vocab)
+    check(g, "text768/word_emb", word, rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(sent.numpy(), g["text768/sent_emb"], rtol=1e-5, atol=1e-6)
 
 
 def test_float64_agrees_with_float32():
