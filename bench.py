@@ -11,11 +11,15 @@ random-init weights).  The global batch is fixed, so N ranks each take 256 / N p
 text embeddings are all-gathered so every rank sees all 256 negatives.
 
 Prints ONE JSON line (rank 0).  `roofline` describes the dominant hand-written kernel, K1
-(k_local_attn_fwd: fused region x word attention similarity): achieved = algorithmic FLOPs per launch
-((4*S*D + 6*D) * B_img * sum(cap_lens)) / mean launch time measured with events on the
-launch stream inside the timed region; peak = 2.5 PFLOP/s dense bf16 MFMA (MI355X_MICROARCH.md).
-`cpu_baseline` times the reference-structured CPU restatement (oracle/, "port") of the same training
-step on the host cores at B = 16 (BASELINE.json configs[0] shape), rank 0, N = 1 only.
+(glr_local_attn_fwd: fused region x word attention similarity): achieved = algorithmic FLOPs per launch
+((4*S*D + 6*D) * B_img * sum(cap_lens)) / mean launch time measured with HIP events on the
+launch stream inside the timed region; peak = 2.5 PFLOP/s dense bf16 MFMA (MI355X_MICROARCH.md).  Two
+brackets are reported: `launch_ms` / `frac` around the K1 launches alone and `op_ms` / `frac_op` around the
+whole forward op (operand packing + Gram GEMM + K-tiling + K1).  `loss_path` gives the K1 backward launch,
+the backward op (launch + the three gradient GEMMs + scatter) and the share of library GEMMs in it.
+`cpu_baseline` times the reference-structured CPU restatement (oracle/, "port") on the host cores, rank 0,
+N = 1 only: the full training step at B = 16 (BASELINE.json configs[0]) as `value`, plus the loss alone
+(forward + backward at B = 16 / 64, forward at B = 256) - medians, thread count = all host cores.
 """
 
 import argparse
@@ -54,20 +58,29 @@ def build(cfg_batch, precision, device, dist_ctx, bert_layers=12, miopen_benchma
     return cfg, model, trainer
 
 
-def cpu_baseline(sample_batch=16, steps=1):
-    """Reference-structured CPU training step (oracle loss + the same torch encoders on CPU)."""
+def _median(xs):
+    xs = sorted(xs)
+    return xs[len(xs) // 2]
+
+
+def cpu_baseline(sample_batch=16, steps=3):
+    """Reference-structured CPU path: the oracle's per-sentence loss loop + the same torch encoders
+    on the host cores.  Bounded sample: `steps` full training steps at B = 16 after one warm-up (median), and the
+    loss alone on synthetic embeddings: forward + backward at B = 16 / 64 (median of 5 / 3), forward at B = 256."""
     from gloria import builder
     from gloria.config import pretrain_config
     from gloria.datasets.synthetic import make_batch
     from oracle import gloria_oracle as orc
+    import numpy as np
+    cores = os.cpu_count() or torch.get_num_threads()
+    torch.set_num_threads(cores)
     cfg = pretrain_config("imagenome", batch_size=sample_batch)
     torch.manual_seed(1234)
     model = builder.build_gloria_model(cfg)
     model.train()
     params = [p for p in model.parameters() if p.requires_grad]
     opt = torch.optim.Adam(params, lr=5e-5, weight_decay=1e-6, betas=(0.5, 0.999))
-    batch = make_batch(sample_batch, seed=1234)
-    cores = torch.get_num_threads()
+    batch = make_batch(sample_batch, seed=1234, lengths="words")
     times = []
     for it in range(steps + 1):                  # first iteration = warm-up (allocator, MKL init)
         t0 = time.perf_counter()
@@ -78,10 +91,37 @@ def cpu_baseline(sample_batch=16, steps=1):
         torch.nn.utils.clip_grad_norm_(params, 0.25)
         opt.step()
         times.append(time.perf_counter() - t0)
-    best = min(times[1:]) if len(times) > 1 else times[0]
-    return {"value": sample_batch / best, "unit": "pairs/s", "cores": cores, "kind": "port",
-            "sample": f"{steps} full training step(s) (ResNet-50 + BERT-base fwd/bwd + reference-structured "
-                      f"local/global loss loop + clip + Adam) at B={sample_batch}, fp32, torch CPU ops, after 1 warm-up step"}
+    step_s = _median(times[1:])
+    del model, opt, params
+
+    def loss_only(B, backward, reps):
+        g = torch.Generator().manual_seed(1234 + B)
+        img = (torch.randn(B, 768, 19, 19, generator=g) * 0.5).requires_grad_(backward)
+        words = (torch.randn(B, 768, 97, generator=g) * 0.5).requires_grad_(backward)
+        ig = (torch.randn(B, 768, generator=g) * 0.5).requires_grad_(backward)
+        tg = (torch.randn(B, 768, generator=g) * 0.5).requires_grad_(backward)
+        lens = sorted((int(x) + 1 for x in np.random.default_rng(1234).integers(4, 40, size=B)), reverse=True)
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            with torch.set_grad_enabled(backward):
+                l = orc.local_loss(img, words, lens)
+                gl_ = orc.global_loss(ig, tg)
+                tot = l[0] + l[1] + gl_[0] + gl_[1]
+            if backward:
+                tot.backward()
+                img.grad = words.grad = ig.grad = tg.grad = None
+            ts.append(time.perf_counter() - t0)
+        return _median(ts)
+
+    loss = {"B16_fwd_bwd_s": loss_only(16, True, 5), "B64_fwd_bwd_s": loss_only(64, True, 3),
+            "B256_fwd_s": loss_only(256, False, 1)}
+    return {"value": sample_batch / step_s, "unit": "pairs/s", "cores": cores, "kind": "port",
+            "sample": f"median of {steps} full training steps (ResNet-50 + BERT-base fwd/bwd + reference-structured "
+                      f"per-sentence local/global loss loop + clip + Adam) at B={sample_batch}, fp32, torch CPU ops, "
+                      f"after 1 warm-up step; loss_only = the loss loop alone on synthetic embeddings "
+                      f"(median of 5 / 3 / 1 runs)",
+            "step_s": step_s, "loss_only": loss}
 
 
 def main():
@@ -90,7 +130,9 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
-    ap.add_argument("--lengths", default="mix", choices=["mix", "max"])
+    ap.add_argument("--lengths", default="words", choices=["words", "mix", "max"],
+                    help="words: caption WORD counts ~ U{4..39} (SURVEY.md 8d, the metric's workload); mix: round 1's "
+                         "word-PIECE counts ~ U{4..39}; max: every caption at the 97-token limit")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--bert-layers", type=int, default=12)
     ap.add_argument("--global-batch", type=int, default=GLOBAL_BATCH,
@@ -132,23 +174,44 @@ def main():
     for _ in range(args.warmup):
         trainer.training_step(model, batch)
     sync()
-    GL.K1_EVENTS = []
+    GL.PROFILE = {}
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = trainer.training_step(model, batch)
     sync()
     elapsed = time.perf_counter() - t0
-    events, GL.K1_EVENTS = GL.K1_EVENTS, None
+    prof, GL.PROFILE = GL.PROFILE, None
     if dctx:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    k1_ms = [a.elapsed_time(b) for a, b, _ in events]
-    k1_flops = [f for _, _, f in events]
-    k1_mean_s = sum(k1_ms) / max(len(k1_ms), 1) / 1e3
-    achieved = (sum(k1_flops) / max(len(k1_flops), 1)) / k1_mean_s / 1e12 if k1_ms else 0.0
+    def mean_ms(key):
+        ev = prof.get(key, [])
+        return sum(a.elapsed_time(b) for a, b in ev) / len(ev) if ev else None
+
+    k1_ms, k1_op_ms = mean_ms("k1_fwd"), mean_ms("k1_fwd_op")
+    k1_bwd_ms, k1_bwd_op_ms = mean_ms("k1_bwd"), mean_ms("k1_bwd_op")
+    flops = prof.get("k1_flops", [])
+    mean_flops = sum(flops) / len(flops) if flops else 0.0
     peak = (PEAK_BF16_MFMA if args.precision == "bf16" else PEAK_F32_MFMA) / 1e12
+    achieved = mean_flops / (k1_ms * 1e-3) / 1e12 if k1_ms else 0.0
+    achieved_op = mean_flops / (k1_op_ms * 1e-3) / 1e12 if k1_op_ms else 0.0
+
+    # kernel launches of one step (outside the timed region; the step floor at small per-GPU batches is launch bound)
+    launches = None
+    if rank == 0:
+        try:
+            from torch.profiler import ProfilerActivity, profile
+            with profile(activities=[ProfilerActivity.CUDA]) as tp:
+                trainer.training_step(model, batch)
+                torch.cuda.synchronize()
+            launches = sum(1 for e in tp.events() if e.device_type == torch.autograd.DeviceType.CUDA)
+        except Exception:      # noqa: BLE001 - the count is informational
+            launches = None
+    # sum of cap_lens (words + [CLS]) of the global batch, recovered from the algorithmic FLOP count of one launch
+    s_eff = 361 + (1 if cfg.model.gloria.no_attn_vec else 0)
+    cap_lens_sum = round(mean_flops / ((4.0 * s_eff * 768 + 6.0 * 768) * per_rank)) if mean_flops else None
 
     if rank == 0:
         rec = {
@@ -168,16 +231,20 @@ def main():
                                    "contrastive loss, full training step (fwd+bwd+clip+Adam)",
                        "global_batch": GB, "per_gpu_batch": per_rank, "image": "224x224 -> 299x299",
                        "tokens": 97, "caption_lengths": args.lengths, "miopen_find_db": bool(use_find),
+                       "kernel_launches_per_step": launches, "sum_cap_lens": cap_lens_sum,
                        "parallelism": f"dp{world}" + (" (text-embedding all-gather + grad all-reduce, RCCL)" if world > 1 else ""),
                        "final_loss": float(loss)},
-            "roofline": {"bound": "mfma", "kernel": "k_local_attn_fwd (K1)", "achieved": achieved, "peak": peak,
-                         "unit": "TFLOP/s", "frac": achieved / peak if peak else None,
-                         # L2-side fabric bytes per launch from rocprofv3 PMC passes of this kernel at this shape
-                         # (FETCH_SIZE 977,733 KB x2 gfx950 read correction + WRITE_SIZE 23,976 KB;
-                         # profiles/r01_k1_pair_pmc_counters_v6.txt).  Infinity-Cache hits are counted: the 235 MB of
-                         # operands fit the 256 MiB cache, the excess is word tiles re-read per image group
-                         "traffic": 1.98e9 if (world == 1 and args.precision == "bf16" and args.lengths == "mix") else None,
-                         "launch_ms": k1_mean_s * 1e3, "launches": len(k1_ms)},
+            "roofline": {"bound": "mfma", "kernel": "glr_local_attn_fwd (K1: k_local_attn_pw + single-tile launches)",
+                         "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak if peak else None,
+                         "launch_ms": k1_ms, "launches": len(prof.get("k1_fwd", [])),
+                         "algorithmic_flops_per_launch": mean_flops,
+                         # whole forward op: operand packing + Gram GEMM + K-tiling + K1 (same algorithmic FLOPs)
+                         "op_ms": k1_op_ms, "achieved_op": achieved_op, "frac_op": achieved_op / peak if peak else None,
+                         # HBM-side bytes per launch come from the rocprofv3 PMC passes committed under profiles/
+                         # (FETCH_SIZE in its own pass, x2 gfx950 correction); not measured by this run
+                         "traffic": None},
+            "loss_path": {"k1_bwd_launch_ms": k1_bwd_ms, "k1_bwd_op_ms": k1_bwd_op_ms,
+                          "k1_bwd_library_gemm_share": (1.0 - k1_bwd_ms / k1_bwd_op_ms) if (k1_bwd_ms and k1_bwd_op_ms) else None},
         }
         if world == 1 and not args.no_cpu_baseline:
             # free the GPU-side model first; the CPU leg builds its own copy

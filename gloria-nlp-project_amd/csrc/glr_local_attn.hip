@@ -39,6 +39,7 @@
 // Accumulator element q of a block: word row (q&3) + 8*(q>>2) + 4*(lane>>5), region column lane&31.
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 
 #include "glr_common.h"
 
@@ -85,8 +86,10 @@ struct LaParams {
   int strip;
   int pair_only, img_offset;
   int img_block;                // pair kernel: images per L2 group (block -> (image, item) mapping)
-  int t4;                       // experimental 4-wave kernel active (GLR_K1_T4=1)
-  const unsigned char *vt_f, *gram_f, *tp_f;   // its fragment-major operands (glr_tile_frag)
+  const unsigned* rowflags;     // [n_tiles][8] run boundaries per tile and lane half (glr_plan_rowflags), pair kernel
+#ifdef GLR_ABLATE
+  int dbg;                      // diagnostic build only (libglr_ablate.so): phases to SKIP, GLR_K1_DBG bit mask
+#endif
   // backward only
   const float* dsim;            // [B_img][ld_sim]
   unsigned char* xout;          // [n_slots][B_img][S_pad] op dtype
@@ -134,6 +137,13 @@ __device__ unsigned long long* g_wave_stamps = nullptr;
 #define GLR_STAMP2(i)
 #define GLR_WSTAMP(c, k)
 #endif
+// timing-only diagnostic build (make ablate): a phase is skipped when its bit is set in GLR_K1_DBG - results are
+// garbage, only the run time matters (tools/ablate_k1.py); never compiled into libglr.so
+#ifdef GLR_ABLATE
+#define GLR_SKIP(bit) (p.dbg & (bit))
+#else
+#define GLR_SKIP(bit) false
+#endif
 
 __device__ __forceinline__ unsigned lds_addr(const void* p) {
   return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const unsigned char*)p;
@@ -174,8 +184,10 @@ constexpr int NBUF = 4;     // ring depth
 // buffer is the target of the DMA for chunk c+PD issued right after the barrier.
 // Measured (tools/stamps_k1.py): the streams run at ~27 B/clk/CU of L2->LDS DMA issue, independent of the
 // prefetch depth and of reading fragments one chunk ahead; fewer DMA-issuing waves are slower.
+// A rows of this wave: ring / image row `arow0 + (lane & 31)` feeds acc; with NH == 2 a second 32-row block
+// `a2_delta` BYTES further on feeds acc2 (another tile's rows, or the second word block of the same tile).
 template <typename O, bool A_RES, int NPWC, int NH = 1, int NB = NBUF>
-__device__ __forceinline__ void stream_gemm_n(f32x16 (&acc)[3], f32x16 (&acc2)[3], int img2_off, unsigned char* ring,
+__device__ __forceinline__ void stream_gemm_n(f32x16 (&acc)[3], f32x16 (&acc2)[3], int arow0, int a2_delta, unsigned char* ring,
                                               int buf_bytes,
                                               const unsigned char* asrc, size_t apitch,
                                               const unsigned char* bsrc, size_t bpitch, int brows, int nchunk,
@@ -235,13 +247,13 @@ __device__ __forceinline__ void stream_gemm_n(f32x16 (&acc)[3], f32x16 (&acc2)[3
   auto compute = [&](int c) {
     const unsigned char* rb = ring + (c % NB) * buf_bytes;
     if (active) {
-      const unsigned char* aa0 = A_RES ? (aimg + (wm * 32 + l31) * aimg_pitch + c * CHB + h * 16)
-                                       : (rb + (wm * 32 + l31) * CHB);
+      const unsigned char* aa0 = A_RES ? (aimg + (arow0 + l31) * aimg_pitch + c * CHB + h * 16)
+                                       : (rb + (arow0 + l31) * CHB);
       typename O::frag fa[KSTEPS], fa2[KSTEPS], fb[KSTEPS][3];
 #pragma unroll
       for (int kk = 0; kk < KSTEPS; ++kk) {
         fa[kk] = A_RES ? O::ld(aa0 + kk * 32) : O::ld(aa0 + koff[kk]);
-        if (NH == 2) fa2[kk] = A_RES ? O::ld(aa0 + img2_off + kk * 32) : O::ld(aa0 + tw * CHB + koff[kk]);
+        if (NH == 2) fa2[kk] = A_RES ? O::ld(aa0 + a2_delta + kk * 32) : O::ld(aa0 + a2_delta + koff[kk]);
 #pragma unroll
         for (int j = 0; j < 3; ++j) fb[kk][j] = O::ld(rb + bofs[j] + koff[kk]);
       }
@@ -284,7 +296,7 @@ __device__ __forceinline__ void stream_gemm_n(f32x16 (&acc)[3], f32x16 (&acc2)[3
 }
 
 template <typename O, bool A_RES, int NH = 1, int NB = NBUF>
-__device__ __forceinline__ void stream_gemm(f32x16 (&acc)[3], f32x16 (&acc2)[3], int img2_off, unsigned char* ring,
+__device__ __forceinline__ void stream_gemm(f32x16 (&acc)[3], f32x16 (&acc2)[3], int arow0, int a2_delta, unsigned char* ring,
                                             int buf_bytes, const unsigned char* asrc, size_t apitch,
                                             const unsigned char* bsrc, size_t bpitch, int brows, int nchunk,
                                             const unsigned char* aimg, int aimg_pitch, int wave, int lane, int wm,
@@ -292,7 +304,7 @@ __device__ __forceinline__ void stream_gemm(f32x16 (&acc)[3], f32x16 (&acc2)[3],
   constexpr int RPI = 64 / (CHB / 16);
   const int winstr = ((A_RES ? 0 : NH * tw) + brows) / RPI;
   const int npw = (winstr + 7) / 8;                      // workgroup-uniform
-#define GLR_SG(N) stream_gemm_n<O, A_RES, N, NH, NB>(acc, acc2, img2_off, ring, buf_bytes, asrc, apitch, bsrc, bpitch, brows, \
+#define GLR_SG(N) stream_gemm_n<O, A_RES, N, NH, NB>(acc, acc2, arow0, a2_delta, ring, buf_bytes, asrc, apitch, bsrc, bpitch, brows, \
                                                  nchunk, aimg, aimg_pitch, wave, lane, wm, wg, nrb, tw)
   switch (npw) {
     case 1: GLR_SG(1); break;
@@ -462,7 +474,7 @@ __global__ void __launch_bounds__(NTHR) k_local_attn(LaParams p) {
     for (int j = 0; j < 3; ++j)
 #pragma unroll
       for (int q = 0; q < 16; ++q) acc[j][q] = 0.f;
-    stream_gemm<O, false>(acc, acc, 0, ring, buf1, p.tp + (size_t)tile * TW * rowbytes1, rowbytes1, vt_b, rowbytes1, S_pad,
+    stream_gemm<O, false>(acc, acc, wm * 32, 0, ring, buf1, p.tp + (size_t)tile * TW * rowbytes1, rowbytes1, vt_b, rowbytes1, S_pad,
                           nch1, nullptr, 0, wave, lane, wm, wg, nrb, tw);
 
     GLR_STAMP(1);
@@ -632,7 +644,7 @@ __global__ void __launch_bounds__(NTHR) k_local_attn(LaParams p) {
 
     GLR_STAMP(3);
     // ================= P3: acc[w, r] (+)= image . G^T =================
-    stream_gemm<O, true>(acc, acc, 0, ring, buf2, nullptr, 0, gram_b, rowbytes2, S_pad, nch2, img, IMP, wave, lane, wm, wg,
+    stream_gemm<O, true>(acc, acc, wm * 32, 0, ring, buf2, nullptr, 0, gram_b, rowbytes2, S_pad, nch2, img, IMP, wave, lane, wm, wg,
                          nrb, tw);
 
     GLR_STAMP(4);
@@ -833,28 +845,36 @@ __global__ void __launch_bounds__(NTHR) k_local_attn(LaParams p) {
 }
 
 // ------------------------------------------------------------------------------------------
-// Forward for a PAIR of ordinary tiles (128 words) of one image: vt[b] AND gram[b] are streamed once
-// for both tiles (the streams are L2->LDS bandwidth bound, ~27 B/clk/CU, so bytes per word decide the
-// time).  Both tiles' scores stay in registers (2 x 48 fp32) from P1 to P2.
+// Forward for a PAIR of tiles, wave-owned words (the production forward for the 384-region shape, bf16).
 //
-// Word softmax statistics WITHOUT a score tile in LDS: in the accumulator layout a lane owns 16 words of
-// one region column, and the words of a sentence are a run along the register index, so each lane reduces
-// its runs in registers and publishes one value per (run, region):
-//   pass 1  run maximum  -> ds_max_f32 on mx[sentence][region]           (exact, order independent)
-//   pass 2  run sum of exp(s - max) -> plain store to ps[word block, half wave][sentence][region]
-//           (one writer per entry; the four partial tables are summed in fixed order afterwards:
-//            bitwise reproducible)
-// LDS:  [0, 2*IMG)      images of tile A and B   | earlier: P1 ring, then the mx / ps tables
-//       [2*IMG, +TAB)   lse tables (log2 units) [PAIR_MAXSEG][S_pad] | later: the 2-deep P3 ring
-//       small           segment tables, reductions
-// A pair holds at most PAIR_MAXSEG sentences in total (planner: glr_plan_items).
-constexpr int PAIR_MAXSEG = 16;
-constexpr int T4_MAXSEG_FWD = 8;   // (see k_local_attn_t4)
+// One 512-thread workgroup = one image x a PAIR of 64-slot word tiles: vt[b] and gram[b] pass through LDS once per 128
+// words (the streams are bound by the L2 -> LDS path, ~48 B/clk/CU, so bytes per word decide their time).  The eight
+// waves are mapped  wave -> (tile t = wave & 1, region group wg = wave >> 1): a wave holds ALL 64 word slots of its tile
+// (two 32-word MFMA blocks, acc0 / acc1) for its three region blocks.  The word softmax (a1 = softmax over the
+// words of a sentence, per region) is then private to the wave: every (sentence, region column) statistic is
+// combined between the two lane halves of ONE wave, through a table only that wave touches.  No workgroup barrier
+// and no finalize loop between the end of the score stream and the completed e2 image.
+//
+// Rows.  Lane half h owns the slots w with ((w >> 2) & 1) == h: 32 rows in word order, row k < 16 = acc0[.][k],
+// k >= 16 = acc1[.][k - 16].  A sentence is a run of rows; where runs start / end is the same for all lanes of a
+// half and comes from the planner as bit masks (glr_plan_rowflags), so the fully unrolled row loops branch on
+// SCALAR bits and do per-lane work only at run boundaries:
+//   pass 1  running max; at a run end  plain store -> mx[lane half][sentence][region]      (log2 units)
+//   pass 2  running sum of exp2(s log2e - max); at a run end plain store -> sm[lane half][sentence][region]
+//           (one writer per entry; readers combine the two halves in a fixed order: bitwise reproducible)
+//   P2      at a run start lse = mx + log2(sm) (the owner half also stores it for the backward pass); per element
+//           a1 = exp2(s log2e - lse), e2 = exp2(temp1 log2e a1) -> bf16 image [word][region]; dot~ by DPP row sums
+// Z_w = sum_r e2[w, r] is NOT reduced on the vector ALU: the packed Gram operand carries ones in row S_pad - 1
+// (a padded region: columns r < S_eff), so the second MFMA contraction leaves Z_w in output column S_pad - 1.
+// A sentence of 65..128 words owns both tiles: its two tiles keep separate table rows (row = tile) that are
+// combined in a fixed order behind a workgroup barrier (the only case with barriers inside the statistics).
+// LDS: [0, 2*IMG) images (earlier: P1 ring) | [2*IMG, +48 KiB) mx / sm half tables, then the 2-deep P3 ring | small.
+constexpr int PW_MAXSEG = 8;    // sentences per pair (planner: max_pair_seg); the spanning sentence of a long pair uses rows 0 / 1
 
 template <typename O>
-__global__ void __launch_bounds__(NTHR) k_local_attn_pair(LaParams p) {
+__global__ void __launch_bounds__(NTHR) k_local_attn_pw(LaParams p) {
   constexpr int ESZ = O::ESZ, CB = CHB;
-  constexpr int SP = GLR_MAX_SPAD;               // this kernel is built for S_pad == GLR_MAX_SPAD only (launch_pair checks)
+  constexpr int SP = GLR_MAX_SPAD;
   constexpr int NRB = SP / 32;
   constexpr int IMP = SP * ESZ + 16;
   constexpr int IMG = TW * IMP;
@@ -864,13 +884,12 @@ __global__ void __launch_bounds__(NTHR) k_local_attn_pair(LaParams p) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave & 1, wg = wave >> 1;
+  const int t = wave & 1, wg = wave >> 1;
   const int l31 = lane & 31, h = lane >> 5;
 
   // Block -> (image, item).  Blocks with equal blockIdx % 8 share an XCD (speed only).  Per XCD the blocks walk
   // groups of `img_block` images x all items, images innermost: the XCD's concurrently resident workgroups then
-  // share img_block images (vt + gram: 885 KB each) AND a few word-tile pairs (196 KB each) in the 4 MiB L2,
-  // instead of re-fetching all 9 MB of packed words from the Infinity Cache for every single image.
+  // share img_block images (vt + gram: 885 KB each) AND a few word-tile pairs (196 KB each) in the 4 MiB L2.
   const int xcd = blockIdx.x & 7, qq = blockIdx.x >> 3;
   const int ib = p.img_block;
   const int grp = qq / (ib * p.n_items), rem = qq - grp * (ib * p.n_items);
@@ -882,15 +901,17 @@ __global__ void __launch_bounds__(NTHR) k_local_attn_pair(LaParams p) {
 
   unsigned char* ring = smem;
   unsigned char* img0 = smem;
-  float* ps = reinterpret_cast<float*>(smem);                    // [4][PAIR_MAXSEG][SP] partial sums per (word block, half wave)
-  float* tab = reinterpret_cast<float*>(smem + p.off_img);       // [PAIR_MAXSEG][SP]   lse, log2 units
-  float* mx = tab + PAIR_MAXSEG * SP;                            // [PAIR_MAXSEG][SP]   segment maxima, log2 units
+  // statistics tables, one writer per entry (plain stores: LDS float atomics cost ~50 LDS cycles per wave
+  // instruction and stall every other LDS access of the CU): [lane half][sentence][region]
+  float* mx = reinterpret_cast<float*>(smem + p.off_img);        // [2][PW_MAXSEG][SP] run maxima, log2 units
+  float* sm = mx + 2 * PW_MAXSEG * SP;                           // [2][PW_MAXSEG][SP] run sums of exp2
+  constexpr int HT = PW_MAXSEG * SP;                             // floats from one half's table to the other's
   unsigned char* ring3 = smem + p.off_img;
   signed char* wsegb = reinterpret_cast<signed char*>(smem + p.off_small);   // [2 * TW] sentence index in the pair, -1 = empty
-  int* seg_w0 = reinterpret_cast<int*>(wsegb + 2 * TW);          // [PAIR_MAXSEG] first slot (0..127)
-  int* seg_n = seg_w0 + PAIR_MAXSEG;
-  int* seg_sent = seg_n + PAIR_MAXSEG;
-  int* misc = seg_sent + PAIR_MAXSEG;                            // [0] = sentences in the pair, [1..2] diagonal w0, n
+  int* seg_w0 = reinterpret_cast<int*>(wsegb + 2 * TW);
+  int* seg_n = seg_w0 + PW_MAXSEG;
+  int* seg_sent = seg_n + PW_MAXSEG;
+  int* misc = seg_sent + PW_MAXSEG;                              // [0] = sentences in the pair, [1..2] diagonal w0, n
   float* tnl = reinterpret_cast<float*>(misc + 16);              // [2 * TW] word norms
   float* zsum = tnl + 2 * TW;                                    // [2 * TW]
   float* dsum = zsum + 2 * TW;                                   // [2 * TW]
@@ -900,21 +921,19 @@ __global__ void __launch_bounds__(NTHR) k_local_attn_pair(LaParams p) {
   const unsigned char* vt_b = p.vt + (size_t)b * SP * rowbytes1;
   const unsigned char* gram_b = p.gram + (size_t)b * SP * rowbytes2;
 
-  // ---- segment tables of both tiles (sentence index = position in the pair)
   if (tid < 2 * TW) {
     wsegb[tid] = -1;
     tnl[tid] = p.tnorm[(size_t)tile0 * TW + tid];
   }
   if (tid < 3) misc[tid] = 0;
-  // a pair is either two ordinary tiles or ONE sentence of 65..128 words that owns both tiles (the planner lists
-  // it once per tile): a single segment spanning tile A and B
   const bool long_pair = p.tile_nsub[tile0] == 2;
-  if (p.t4 && !long_pair && p.tile_first[tile0 + 1] - p.tile_first[tile0] <= T4_MAXSEG_FWD &&
-      p.tile_first[tile0 + 2] - p.tile_first[tile0 + 1] <= T4_MAXSEG_FWD)
-    return;                                      // experimental: the 4-wave kernel runs this pair's tiles
   {
     const int sf0 = p.tile_first[tile0], sf2 = p.tile_first[tile0 + 2];
     const int ns = long_pair ? 1 : sf2 - sf0;
+    if (ns > PW_MAXSEG) {                        // planner contract violated (glr_plan_items max_pair_seg <= 8): fail loudly
+      if (tid < ns) p.sim[(size_t)b * p.ld_sim + p.order[sf0 + tid]] = __builtin_nanf("");
+      return;
+    }
     if (tid == 0) misc[0] = ns;
     if (tid < ns) {
       const int sent = p.order[sf0 + tid];
@@ -930,198 +949,262 @@ __global__ void __launch_bounds__(NTHR) k_local_attn_pair(LaParams p) {
     for (int w = 0; w < n; ++w) wsegb[w0 + w] = (signed char)tid;
     if (seg_sent[tid] == p.img_offset + b) { misc[1] = w0; misc[2] = n; }
   }
-
   // ================= P1 (both tiles, one stream of vt[b]) =================
-  f32x16 accA[3], accB[3];
+  f32x16 acc0[3], acc1[3];
 #pragma unroll
   for (int j = 0; j < 3; ++j)
 #pragma unroll
-    for (int q = 0; q < 16; ++q) { accA[j][q] = 0.f; accB[j][q] = 0.f; }
+    for (int q = 0; q < 16; ++q) { acc0[j][q] = 0.f; acc1[j][q] = 0.f; }
   __syncthreads();
   GLR_STAMP2(1);
-  stream_gemm<O, false, 2>(accA, accB, 0, ring, (2 * TW + SP) * CB, p.tp + (size_t)tile0 * TW * rowbytes1, rowbytes1,
-                           vt_b, rowbytes1, SP, (int)(rowbytes1 / CB), nullptr, 0, wave, lane, wm, wg, NRB, TW);
+  if (!GLR_SKIP(1))
+  stream_gemm<O, false, 2>(acc0, acc1, t * TW, 32 * CB, ring, (2 * TW + SP) * CB, p.tp + (size_t)tile0 * TW * rowbytes1,
+                           rowbytes1, vt_b, rowbytes1, SP, (int)(rowbytes1 / CB), nullptr, 0, wave, lane, 0, wg, NRB, TW);
   GLR_STAMP2(2);
 
-  // ================= word-softmax statistics from the scores in registers =================
-  // partial-sum tables: one per (word block, half wave) - and per tile for the spanning sentence of a long pair
-  const int n_ps = long_pair ? 8 : 4, ps_stride = long_pair ? SP : PAIR_MAXSEG * SP;
-  for (int i = tid; i < NS * SP; i += NTHR) {
-    mx[i] = -INFINITY;
-    for (int k = 0; k < n_ps; ++k) ps[k * ps_stride + i] = 0.f;
-  }
-  // sentence ids of this lane's 16 word rows of tile t: word = wm*32 + (q&3) + 8*(q>>2) + 4*h, so the four
-  // rows of a q-group are four consecutive bytes
-  int sgA[4], sgB[4];
-#pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    sgA[g] = *reinterpret_cast<const int*>(wsegb + wm * 32 + 4 * h + 8 * g);
-    sgB[g] = *reinterpret_cast<const int*>(wsegb + TW + wm * 32 + 4 * h + 8 * g);
-  }
-#define GLR_SGQ(pk, q) (((pk)[(q) >> 2] << (24 - 8 * ((q) & 3))) >> 24)
-  __syncthreads();
-  const int rbase = wg * 32 + l31;              // this lane's region in block j: rbase + 128 * j
-  // pass 1: run maxima (log2 units) -> ds_max_f32.  A run ends where the next row has another sentence.
-  auto run_max = [&](f32x16 (&acc)[3], const int (&pk)[4]) {
-    float rm[3] = {-INFINITY, -INFINITY, -INFINITY};
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const int sg = GLR_SGQ(pk, q);
-      const bool last = (q == 15) || (GLR_SGQ(pk, (q + 1) & 15) != sg);
-#pragma unroll
-      for (int j = 0; j < 3; ++j) rm[j] = fmaxf(rm[j], acc[j][q]);
-      if (last && sg >= 0) {
-        float* dst = mx + sg * SP + rbase;
-#pragma unroll
-        for (int j = 0; j < 3; ++j)
-          __hip_atomic_fetch_max(dst + 128 * j, rm[j] * LOG2E, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      }
-#pragma unroll
-      for (int j = 0; j < 3; ++j) rm[j] = last ? -INFINITY : rm[j];
-    }
-  };
-  run_max(accA, sgA);
-  run_max(accB, sgB);
-  __syncthreads();
-  GLR_STAMP2(3);
-  // pass 2: run sums of exp2(s*log2e - max) -> ds_add_f32 (the maximum of every element's sentence is one
-  // independent LDS read per element: no serial dependence on the run bookkeeping)
-  // (LDS float-add atomics measured ~60 cycles per wave instruction here; every (word block, half wave,
-  //  sentence, region) has exactly one writer, so plain stores into four partial tables do the same job)
-  auto run_sum = [&](f32x16 (&acc)[3], const int (&pk)[4], int t) {
-    float* psw = ps + ((long_pair ? 4 * t : 0) + wm * 2 + h) * ps_stride;
-    float rs[3] = {0.f, 0.f, 0.f}, nx[3];
-    {
-      const float* src = mx + max(GLR_SGQ(pk, 0), 0) * SP + rbase;
-#pragma unroll
-      for (int j = 0; j < 3; ++j) nx[j] = src[128 * j];
-    }
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const int sg = GLR_SGQ(pk, q);
-      const bool last = (q == 15) || (GLR_SGQ(pk, (q + 1) & 15) != sg);
-      float m2[3];
-#pragma unroll
-      for (int j = 0; j < 3; ++j) m2[j] = nx[j];
-      if (q < 15) {                              // next row's maxima are in flight while this row computes
-        const float* src = mx + max(GLR_SGQ(pk, (q + 1) & 15), 0) * SP + rbase;
-#pragma unroll
-        for (int j = 0; j < 3; ++j) nx[j] = src[128 * j];
-      }
-#pragma unroll
-      for (int j = 0; j < 3; ++j) rs[j] += __builtin_amdgcn_exp2f(__builtin_fmaf(acc[j][q], LOG2E, -m2[j]));
-      if (last && sg >= 0) {
-        float* dst = psw + sg * SP + rbase;
-#pragma unroll
-        for (int j = 0; j < 3; ++j) dst[128 * j] = rs[j];
-      }
-#pragma unroll
-      for (int j = 0; j < 3; ++j) rs[j] = last ? 0.f : rs[j];
-    }
-  };
-  run_sum(accA, sgA, 0);
-  run_sum(accB, sgB, 1);
-  __syncthreads();
-  for (int i = tid; i < NS * SP; i += NTHR) {          // all 512 threads, independent entries
-    const int s2 = i / SP, r = i - s2 * SP;
-    float sum = (ps[i] + ps[ps_stride + i]) + (ps[2 * ps_stride + i] + ps[3 * ps_stride + i]);
-    if (long_pair) sum += (ps[4 * ps_stride + i] + ps[5 * ps_stride + i]) + (ps[6 * ps_stride + i] + ps[7 * ps_stride + i]);
-    const float l2 = mx[i] + __builtin_amdgcn_logf(sum);      // v_log_f32 = log2
-    tab[i] = l2;
-    if (p.lse) p.lse[((size_t)b * p.n_sent + seg_sent[s2]) * SP + r] = l2 * LN2;
-  }
-  __syncthreads();
-  GLR_STAMP2(4);
+  // run boundaries of this wave's tile (scalar: same for every lane of a half); loaded after the stream so that
+  // they are not carried (and spilled) through it
+  const unsigned* fl = p.rowflags + (size_t)(tile0 + t) * 8;
+  const unsigned ST0 = fl[0], ST1 = fl[1], LA0 = fl[2], LA1 = fl[3];
+  const unsigned STANY = ST0 | ST1, LAANY = LA0 | LA1;
+  const unsigned STh = h ? ST1 : ST0, LAh = h ? LA1 : LA0;
+  // a wave-uniform bit test the compiler must keep as a SCALAR branch: without the opaque copy it folds the test
+  // into the per-lane predicate below it and every row pays an exec-mask sequence
+// (expected false: run boundaries are rare, so the boundary blocks are laid out of line and the common path falls
+// through instead of taking a branch over them at every row)
+#define GLR_SBIT(mask, k) __builtin_expect(([&] { unsigned b_ = ((mask) >> (k)) & 1u; asm volatile("" : "+s"(b_)); return b_ != 0; }()), 0)
 
-  // ================= P2: a1, e2 from the scores in registers; LDS images; per-word Z and dot~ =================
-  // Branch-free: padded regions (r >= S_eff) have zero vt rows and zero Gram rows/columns, so their e2 only
-  // has to be kept out of Z (mask folded into one fma); empty word slots compute finite garbage that no
-  // sentence ever reads (a select here makes hipcc sink the LDS read + both exps into a per-element branch).
+  // sentence ids of this lane's 32 rows: row k -> slot (k >> 4) * 32 + 8 * ((k & 15) >> 2) + 4 h + (k & 3); the
+  // four rows of a group are four consecutive bytes of the slot table
+  int sgp[8];
+#pragma unroll
+  for (int g = 0; g < 8; ++g) sgp[g] = *reinterpret_cast<const int*>(wsegb + t * TW + (g >> 2) * 32 + 4 * h + 8 * (g & 3));
+#define GLR_SGK(k) ((sgp[(k) >> 2] << (24 - 8 * ((k) & 3))) >> 24)
+  const int rbase = wg * 32 + l31;              // this lane's region in block j: rbase + 128 * j
   const float t1l = p.temp1 * LOG2E;
   const int rslot = wg * 2 + ((lane >> 4) & 1);
-  float okr[3];
+  // the bf16-rounded e2 of both word blocks stay in registers (two per dword) for the |c|^2 sums of P4
+  unsigned e2k0[3][8], e2k1[3][8];
+
+  // Table rows: a sentence's index in the pair.  The ONE sentence of a long pair (65..128 words, both tiles) uses
+  // row = tile instead and its two tiles are combined behind workgroup barriers.  Readers therefore combine "their"
+  // row with a second row: the other tile's (long pair) or a constant neutral row (-inf / 0) kept in the unused
+  // half of `red` - one code path for both kinds (a specialised second copy pushed the kernel past the 64 KiB
+  // instruction cache, and so did fat per-row boundary blocks: the combining of lane halves is done once per
+  // sentence in two short rolled loops, fin1 / fin2, not at every run boundary).
+  float* zneg = red + 8 * TW;                   // [SP] -inf   (rows 8..15 of tile 0's partial table: unused here)
+  float* zero = red + 16 * TW + 8 * TW;         // [SP] 0      (rows 8..15 of tile 1's)
+  if (h == 0) {
 #pragma unroll
-  for (int j = 0; j < 3; ++j) okr[j] = (rbase + 128 * j < p.S_eff) ? 1.f : 0.f;
-  // the bf16-rounded e2 of both tiles stay in registers (two per dword) for the |c|^2 sums of P4
-  unsigned e2A[3][8], e2B[3][8];
-  auto p2 = [&](f32x16 (&acc)[3], const int (&pk)[4], int t, unsigned (&e2k)[3][8]) {
-    unsigned char* imgw = img0 + t * IMG + (wm * 32 + 4 * h) * IMP + rbase * ESZ;   // + row(q) * IMP + 128 * j * ESZ
-    float* redt = red + t * 16 * TW + rslot * TW + wm * 32 + 4 * h;               // + 8 * TW (dot) + row(q)
-    float nx[3];
+    for (int j = 0; j < 3; ++j) { zneg[rbase + 128 * j] = -INFINITY; zero[rbase + 128 * j] = 0.f; }
+  }
+  const float* mx2 = (long_pair ? mx + SP : zneg) + rbase;      // second row of the combined maxima
+  const float* sm2 = (long_pair ? sm + SP : zero) + rbase;      // second row of the sums (half 0; half 1 at + HT2)
+  const int HT2 = long_pair ? HT : 0;
+  float* lt = mx + HT;                          // [PW_MAXSEG][SP] lse, log2 units (half-1 maxima are dead after fin1)
+  const int nrow = long_pair ? 2 : NS;
+  {
+    // this wave's table entries - the rows of ITS tile's sentences (the other tile's waves own the same columns),
+    // its columns: every lane half clears its own half tables (a sentence may have no row in a half)
     {
-      const float* src = tab + max(GLR_SGQ(pk, 0), 0) * SP + rbase;
+      float* tm = mx + h * HT + rbase;
+      float* ts = sm + h * HT + rbase;
+      for (int s2 = 0; s2 < nrow; ++s2) {
+        if ((long_pair ? s2 : (seg_w0[s2] >> 6)) != t) continue;
 #pragma unroll
-      for (int j = 0; j < 3; ++j) nx[j] = src[128 * j];
-    }
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const int row = (q & 3) + 8 * (q >> 2);
-      float l2[3];
-#pragma unroll
-      for (int j = 0; j < 3; ++j) l2[j] = nx[j];
-      if (q < 15) {                              // next row's lse values are in flight while this row computes
-        const float* src = tab + max(GLR_SGQ(pk, (q + 1) & 15), 0) * SP + rbase;
-#pragma unroll
-        for (int j = 0; j < 3; ++j) nx[j] = src[128 * j];
+        for (int j = 0; j < 3; ++j) { tm[s2 * SP + 128 * j] = -INFINITY; ts[s2 * SP + 128 * j] = 0.f; }
       }
-      float zacc = 0.f, dacc = 0.f;
+    }
+    if (!GLR_SKIP(2)) {
+    // ---- pass 1: run maxima (v_max_f32 by hand: fmaxf() canonicalises both inputs first, three instructions)
+    {
+      float rm[3] = {-INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+      for (int k = 0; k < 32; ++k) {
+        const f32x16(&acc)[3] = k < 16 ? acc0 : acc1;
+        const int q = k & 15;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) asm("v_max_f32 %0, %1, %2" : "=v"(rm[j]) : "v"(rm[j]), "v"(acc[j][q]));
+        if (GLR_SBIT(LAANY, k)) {
+          const bool mine = (LAh >> k) & 1;
+          if (mine) {
+            float* dst = mx + h * HT + (long_pair ? t : GLR_SGK(k)) * SP + rbase;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) dst[128 * j] = rm[j] * LOG2E;
+          }
+#pragma unroll
+          for (int j = 0; j < 3; ++j) rm[j] = mine ? -INFINITY : rm[j];
+        }
+      }
+    }
+    if (long_pair) __syncthreads();             // the other tile's maxima of the spanning sentence
+    // fin1: maxima of both lane halves -> half-0 table, sentences split between the halves.  (Long pair: the waves
+    // of both tiles own these columns and write identical values; max is idempotent, so the overlap is harmless.)
+    for (int s2 = h; s2 < nrow; s2 += 2) {
+      if (!long_pair && (seg_w0[s2] >> 6) != t) continue;
+      float* e = mx + s2 * SP + rbase;
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
-        const float a1 = __builtin_amdgcn_exp2f(__builtin_fmaf(acc[j][q], LOG2E, -l2[j]));
-        const float e2 = __builtin_amdgcn_exp2f(t1l * a1);
-        O::from_f32(imgw + row * IMP + 128 * j * ESZ, e2);
-        const float e2r = ESZ == 4 ? e2 : bf2f(f2bf(e2));
-        const unsigned eb = __float_as_uint(e2r);                        // low 16 bits are zero
-        e2k[j][q >> 1] = (q & 1) ? (e2k[j][q >> 1] | eb) : (eb >> 16);
-        zacc = __builtin_fmaf(e2r, okr[j], zacc);
-        dacc = __builtin_fmaf(e2r, acc[j][q], dacc);
-        acc[j][q] = 0.f;
-      }
-      const float z = row_sum16(zacc), d = row_sum16(dacc);
-      if ((lane & 15) == 15) {
-        redt[row] = z;
-        redt[8 * TW + row] = d;
+        float m = e[128 * j];
+        const float mb = e[HT + 128 * j];
+        asm("v_max_f32 %0, %1, %2" : "=v"(m) : "v"(m), "v"(mb));
+        e[128 * j] = m;
       }
     }
-  };
-  // NB: the images alias the mx / ps tables, dead now; the lse tables live above the images until the
-  // barrier below, then the P3 ring takes their place
-  p2(accA, sgA, 0, e2A);
-  p2(accB, sgB, 1, e2B);
-  __syncthreads();
+    GLR_STAMP2(3);
+    // ---- pass 2: run sums of exp2(s log2e - max)
+    {
+      float rs[3] = {0.f, 0.f, 0.f}, mc[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+      for (int k = 0; k < 32; ++k) {
+        const f32x16(&acc)[3] = k < 16 ? acc0 : acc1;
+        const int q = k & 15;
+        if (GLR_SBIT(STANY, k)) {
+          const bool mine = (STh >> k) & 1;
+          const float* src = mx + (long_pair ? 0 : max(GLR_SGK(k), 0)) * SP + rbase;
+#pragma unroll
+          for (int j = 0; j < 3; ++j) {
+            float m = src[128 * j];
+            const float m1 = mx2[128 * j];
+            asm("v_max_f32 %0, %1, %2" : "=v"(m) : "v"(m), "v"(m1));
+            mc[j] = mine ? m : mc[j];
+            rs[j] = mine ? 0.f : rs[j];
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) rs[j] += __builtin_amdgcn_exp2f(__builtin_fmaf(acc[j][q], LOG2E, -mc[j]));
+        if (GLR_SBIT(LAANY, k)) {
+          if ((LAh >> k) & 1) {
+            float* dst = sm + h * HT + (long_pair ? t : GLR_SGK(k)) * SP + rbase;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) dst[128 * j] = rs[j];
+          }
+        }
+      }
+    }
+    if (long_pair) __syncthreads();
+    // fin2: lse = max + log2(sum of the halves (and of the second row)), fixed order; stored for the backward pass.
+    // Long pair: one row (0) for the whole sentence, stored by the waves of tile 0.
+    for (int s2 = h; s2 < (long_pair ? 1 : NS); s2 += 2) {
+      if (!long_pair && (seg_w0[s2] >> 6) != t) continue;
+      const float* em = mx + s2 * SP + rbase;
+      const float* es = sm + s2 * SP + rbase;
+      float* dst = (p.lse != nullptr && (!long_pair || t == 0))
+                       ? p.lse + ((size_t)b * p.n_sent + seg_sent[s2]) * SP + rbase : nullptr;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        float m = em[128 * j];
+        const float m1 = mx2[128 * j];
+        asm("v_max_f32 %0, %1, %2" : "=v"(m) : "v"(m), "v"(m1));
+        const float su = (es[128 * j] + es[HT + 128 * j]) + (sm2[128 * j] + sm2[HT2 + 128 * j]);
+        const float l2 = m + __builtin_amdgcn_logf(su);            // v_log_f32 = log2
+        lt[s2 * SP + rbase + 128 * j] = l2;
+        if (dst != nullptr) dst[128 * j] = l2 * LN2;
+      }
+    }
+    if (long_pair) __syncthreads();             // tile 1 reads the row tile 0's waves may still be writing
+    }
+    GLR_STAMP2(4);
+
+    // ---- P2: a1, e2 from the scores in registers; LDS image; per-word dot~
+    // Branch-free per element: padded regions (r >= S_eff) have zero vt rows and zero Gram columns, and the ones
+    // row of the Gram operand only covers r < S_eff, so their e2 reaches neither u nor Z; empty word slots compute
+    // finite garbage that no sentence ever reads.
+    if (!GLR_SKIP(4)) {
+      float lc[3] = {0.f, 0.f, 0.f};
+      unsigned char* imgw = img0 + t * IMG + (4 * h) * IMP + rbase * ESZ;   // + (blk * 32 + row(q)) * IMP + 128 * j * ESZ
+      float* redt = red + t * 16 * TW + rslot * TW + 4 * h;                // + blk * 32 + row(q)
+#pragma unroll
+      for (int blk = 0; blk < 2; ++blk) {
+        f32x16(&acc)[3] = blk == 0 ? acc0 : acc1;
+        unsigned(&e2k)[3][8] = blk == 0 ? e2k0 : e2k1;
+        float dq[16];                           // per-row partial dot~: reduced across lanes after the block (ILP)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int k = blk * 16 + q;
+          const int row = blk * 32 + (q & 3) + 8 * (q >> 2);
+          if (GLR_SBIT(STANY, k)) {
+            const bool mine = (STh >> k) & 1;
+            const float* src = lt + (long_pair ? 0 : max(GLR_SGK(k), 0)) * SP + rbase;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+              const float l2 = src[128 * j];
+              lc[j] = mine ? l2 : lc[j];
+            }
+          }
+          float dacc = 0.f;
+#pragma unroll
+          for (int j = 0; j < 3; ++j) {
+            const float a1 = __builtin_amdgcn_exp2f(__builtin_fmaf(acc[j][q], LOG2E, -lc[j]));
+            const float e2 = __builtin_amdgcn_exp2f(t1l * a1);
+            O::from_f32(imgw + row * IMP + 128 * j * ESZ, e2);
+            const float e2r = ESZ == 4 ? e2 : bf2f(f2bf(e2));
+            const unsigned eb = __float_as_uint(e2r);                      // low 16 bits are zero
+            e2k[j][q >> 1] = (q & 1) ? (e2k[j][q >> 1] | eb) : (eb >> 16);
+            dacc = __builtin_fmaf(e2r, acc[j][q], dacc);
+          }
+          dq[q] = dacc;
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const float d = row_sum16(dq[q]);
+          if ((lane & 15) == 15) redt[blk * 32 + (q & 3) + 8 * (q >> 2)] = d;
+        }
+      }
+    }
+  }
+#undef GLR_SBIT
+  __syncthreads();                              // images complete; the tables are dead: the P3 ring takes their place
   if (tid < 2 * TW) {
     const float* redt = red + (tid >> 6) * 16 * TW + (tid & 63);
-    float z = 0.f, d = 0.f;
+    float d = 0.f;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) { z += redt[k * TW]; d += redt[(8 + k) * TW]; }
-    zsum[tid] = z;
+    for (int k = 0; k < 8; ++k) d += redt[k * TW];
     dsum[tid] = d;
   }
   GLR_STAMP2(5);
 
-  // ================= P3 (both tiles, one stream of gram[b]); 2-deep ring over the dead lse tables =================
-  stream_gemm<O, true, 2, 2>(accA, accB, IMG, ring3, SP * CB, nullptr, 0, gram_b, rowbytes2, SP,
-                            (int)(rowbytes2 / CB), img0, IMP, wave, lane, wm, wg, NRB, TW);
+  // ================= P3 (both word blocks, one stream of gram[b]); first MFMA of every chain starts from zero ====
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) { acc0[j][q] = 0.f; acc1[j][q] = 0.f; }
+  if (!GLR_SKIP(8))
+  stream_gemm<O, true, 2, 2>(acc0, acc1, 0, 32 * IMP, ring3, SP * CB, nullptr, 0, gram_b, rowbytes2, SP,
+                            (int)(rowbytes2 / CB), img0 + t * IMG, IMP, wave, lane, 0, wg, NRB, TW);
   GLR_STAMP2(6);
 
-  // ================= P4: |c|^2, cosine, per-sentence aggregate, diagonal attention maps =================
-  auto p4 = [&](f32x16 (&acc)[3], int t, const unsigned (&e2k)[3][8]) {
-    float* redt = red + t * 16 * TW + rslot * TW + wm * 32 + 4 * h;
+  // ================= P4: Z from the ones row, |c|^2, cosine, per-sentence aggregate, maps =================
+  if (!GLR_SKIP(16)) {
+  if (wg == 3 && l31 == 31) {                   // output column SP - 1 = sum_r<S_eff e2[w, r]
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const int row = (q & 3) + 8 * (q >> 2);
+    for (int k = 0; k < 32; ++k) {
+      const f32x16(&acc)[3] = k < 16 ? acc0 : acc1;
+      const int q = k & 15;
+      zsum[t * TW + (k >> 4) * 32 + (q & 3) + 8 * (q >> 2) + 4 * h] = acc[2][q];
+    }
+  }
+  {
+    const float ok2 = (rbase + 256 < p.S_eff) ? 1.f : 0.f;      // padded columns (incl. the Z column) live in block 2 only
+    float* redt = red + t * 16 * TW + rslot * TW + 4 * h;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) {
+      const f32x16(&acc)[3] = k < 16 ? acc0 : acc1;
+      const unsigned(&e2k)[3][8] = k < 16 ? e2k0 : e2k1;
+      const int q = k & 15;
+      const int row = (k >> 4) * 32 + (q & 3) + 8 * (q >> 2);
       float v = 0.f;
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
         const unsigned u = e2k[j][q >> 1];
-        v += __uint_as_float((q & 1) ? (u & 0xffff0000u) : (u << 16)) * acc[j][q];
+        const float e = __uint_as_float((q & 1) ? (u & 0xffff0000u) : (u << 16));
+        v += (j == 2 ? ok2 * e : e) * acc[j][q];
       }
       v = row_sum16(v);
       if ((lane & 15) == 15) redt[row] = v;
     }
-  };
-  p4(accA, 0, e2A);
-  p4(accB, 1, e2B);
+  }
+  }
   __syncthreads();
   GLR_STAMP2(7);
   if (tid < 2 * TW) {            // waves 0 / 1 = tile A / B, lane = word slot
@@ -1171,14 +1254,12 @@ __global__ void __launch_bounds__(NTHR) k_local_attn_pair(LaParams p) {
     }
   }
   const int dw0 = misc[1], dn = misc[2];
-  if (p.attn != nullptr && dn > 0) {            // the diagonal sentence lies inside one of the two tiles
+  if (p.attn != nullptr && dn > 0) {            // the diagonal sentence lies inside one tile, or spans both (long pair)
     const int sout = p.S_eff - p.strip;
     float* out = p.attn + p.attn_off[p.img_offset + b];
-    const unsigned char* img = img0 + (dw0 >> 6) * IMG;
-    const int dwl = dw0 & 63;
     for (int idx = tid; idx < dn * sout; idx += NTHR) {
-      const int w = idx / sout, r = idx % sout + p.strip;
-      out[idx] = O::to_f32(img + (dwl + w) * IMP + r * ESZ) / zsum[dw0 + w];
+      const int w = dw0 + idx / sout, r = idx % sout + p.strip;
+      out[idx] = O::to_f32(img0 + (w >> 6) * IMG + (w & 63) * IMP + r * ESZ) / zsum[w];
     }
   }
   if (p.amean != nullptr && tid < SP) {
@@ -1187,374 +1268,14 @@ __global__ void __launch_bounds__(NTHR) k_local_attn_pair(LaParams p) {
     const int r = tid;
     for (int s2 = 0; s2 < NS; ++s2) {
       const int w0 = seg_w0[s2], n = seg_n[s2];
-      const unsigned char* col = img0 + (w0 >> 6) * IMG + (w0 & 63) * IMP + r * ESZ;
       float a = 0.f;
-      for (int w = 0; w < n; ++w) a += O::to_f32(col + w * IMP) / zsum[w0 + w];
+      for (int w = w0; w < w0 + n; ++w) a += O::to_f32(img0 + (w >> 6) * IMG + (w & 63) * IMP + r * ESZ) / zsum[w];
       p.amean[((size_t)b * p.n_sent + seg_sent[s2]) * SP + r] = r < p.S_eff ? a / (float)n : 0.f;
     }
   }
   GLR_STAMP2(8);
-#undef GLR_SGQ
+#undef GLR_SGK
 }
-
-// ------------------------------------------------------------------------------------------
-// EXPERIMENTAL forward (GLR_K1_T4=1): one 64-word tile per 256-thread workgroup, TWO workgroups per CU.
-// Wave w owns region blocks {w, w+4, w+8} for BOTH 32-word blocks of the tile (2 x 48 accumulator registers), so
-// every vt / gram row is consumed by exactly one wave: the MFMA fragments of the region operand are loaded
-// straight from L2 into registers (global_load_dwordx4 from the K-tiled operands, three chunks ahead), no LDS
-// ring and no per-chunk barrier; the second workgroup of the CU runs its softmax phases meanwhile.
-// LDS (~77 KiB): [0, 60 KiB) statistics tables, later the e2 image (49 KiB) | lse table 12 KiB | small.
-// Handles ordinary tiles with at most T4_MAXSEG sentences (the pair kernel keeps the rest).
-constexpr int T4_MAXSEG = 8;
-constexpr int T4_NT = 256;
-[[maybe_unused]] constexpr int T4_PF = 3;         // chunks of fragments in flight
-
-struct T4Frags { bf16x8 a0[2], a1[2], b[2][3]; };
-
-__global__ void __launch_bounds__(T4_NT) k_local_attn_t4(LaParams p) {
-  typedef OpBF16 O;
-  constexpr int ESZ = 2;
-  constexpr int SP = GLR_MAX_SPAD;
-  constexpr int IMP = SP * ESZ + 16;
-  constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);        // 0..3
-  const int l31 = lane & 31, h = lane >> 5;
-
-  // block -> (image, pair item, tile of the pair), image groups per XCD as in the pair kernel.
-  // (A persistent variant - 512 workgroups walking the units, the second layer started half a tile late to break the
-  //  lockstep of the two co-resident workgroups - measured 5 % slower than this one-unit-per-workgroup form.)
-  const int xcd = blockIdx.x & 7, qq = blockIdx.x >> 3;
-  const int ib = p.img_block;
-  const int per_grp = ib * p.n_items * 2;
-  const int grp = qq / per_grp, rem = qq - grp * per_grp;
-  const int b = (grp * ib + rem % ib) * 8 + xcd;
-  if (b >= p.B_img) return;
-  const int it = rem / ib;
-  const int tile0 = p.item_tile[it >> 1];
-  if (p.tile_nsub[tile0] != 0) return;                            // a long sentence owns this pair: pair kernel
-  const int tile = tile0 + (it & 1);
-  const int sf = p.tile_first[tile], NS = p.tile_first[tile + 1] - sf;
-  if (p.tile_first[tile0 + 1] - p.tile_first[tile0] > T4_MAXSEG || p.tile_first[tile0 + 2] - p.tile_first[tile0 + 1] > T4_MAXSEG)
-    return;                                                        // pair kernel takes the whole pair
-  const int D = p.D;
-
-  unsigned char* img = smem;
-  float* ps = reinterpret_cast<float*>(smem);                    // [4][T4_MAXSEG][SP]
-  float* mx = ps + 4 * T4_MAXSEG * SP;                           // [T4_MAXSEG][SP]
-  float* tab = mx + T4_MAXSEG * SP;                              // [T4_MAXSEG][SP]   lse, log2 units (survives P2)
-  signed char* wsegb = reinterpret_cast<signed char*>(tab + T4_MAXSEG * SP);   // [TW]
-  int* seg_w0 = reinterpret_cast<int*>(wsegb + TW);
-  int* seg_n = seg_w0 + T4_MAXSEG;
-  int* seg_sent = seg_n + T4_MAXSEG;
-  int* misc = seg_sent + T4_MAXSEG;                              // [1..2] diagonal w0, n
-  float* tnl = reinterpret_cast<float*>(misc + 8);               // [TW]
-  float* zsum = tnl + TW;
-  float* dsum = zsum + TW;
-  float* red = dsum + TW;                                        // [2][8][TW]
-
-  const size_t rowbytes1 = (size_t)D * ESZ, rowbytes2 = (size_t)SP * ESZ;
-  const unsigned char* vt_b = p.vt_f + (size_t)b * SP * rowbytes1;
-  const unsigned char* gram_b = p.gram_f + (size_t)b * SP * rowbytes2;
-  const unsigned char* tp_t = p.tp_f + (size_t)tile * TW * rowbytes1;
-
-  if (tid < TW) { wsegb[tid] = -1; tnl[tid] = p.tnorm[(size_t)tile * TW + tid]; }
-  if (tid < 3) misc[tid] = 0;
-  if (tid < NS) {
-    const int sent = p.order[sf + tid];
-    seg_sent[tid] = sent;
-    seg_w0[tid] = p.sent_slot0[sent] - tile * TW;
-    seg_n[tid] = p.cap_lens[sent];
-  }
-  __syncthreads();
-  if (tid < NS) {
-    const int w0 = seg_w0[tid], n = seg_n[tid];
-    for (int k = 0; k < n; ++k) wsegb[w0 + k] = (signed char)tid;
-    if (seg_sent[tid] == p.img_offset + b) { misc[1] = w0; misc[2] = n; }
-  }
-
-  // ================= P1: scores of both word blocks, operands straight from L2 =================
-  f32x16 acc0[3], acc1[3];
-#pragma unroll
-  for (int j = 0; j < 3; ++j)
-#pragma unroll
-    for (int q = 0; q < 16; ++q) { acc0[j][q] = 0.f; acc1[j][q] = 0.f; }
-  {
-    // fragment-major operands: fragment (chunk c, 32-row block rb, k-step kk) = 1 KiB at ((c * NRB + rb) * 2 + kk) * 1024,
-    // lane i at + 16 i
-    const unsigned char* a_base = tp_t + lane * 16;
-    const unsigned char* b_base = vt_b + (size_t)w * 2048 + lane * 16;
-    auto load = [&](int c, T4Frags& f) {
-      const unsigned char* ac = a_base + (size_t)c * (TW * CHB);           // 2 row blocks x 2 k-steps per chunk = 4 KiB
-      const unsigned char* bc = b_base + (size_t)c * (SP * CHB);           // 12 row blocks per chunk = 24 KiB
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        f.a0[kk] = O::ld(ac + kk * 1024);
-        f.a1[kk] = O::ld(ac + 2048 + kk * 1024);
-#pragma unroll
-        for (int j = 0; j < 3; ++j) f.b[kk][j] = O::ld(bc + (size_t)j * (4 * 2048) + kk * 1024);
-      }
-    };
-    auto mma = [&](const T4Frags& f) {
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-          O::mma(f.a0[kk], f.b[kk][j], acc0[j]);
-          O::mma(f.a1[kk], f.b[kk][j], acc1[j]);
-        }
-    };
-    // D == 768 (checked at launch): 24 chunks, fully unrolled so that hipcc's waitcnt pass counts the loads in flight
-    // exactly (across a loop back-edge it falls back to vmcnt(0), which drains the three-chunk prefetch every trip)
-    constexpr int nch = 768 * ESZ / CHB;
-    T4Frags f0, f1, f2;
-    load(0, f0); load(1, f1); load(2, f2);
-    // the fences pin "MFMAs of chunk c, then the loads of chunk c+3": without them hipcc sinks every load next to
-    // its use and the prefetch distance collapses to a few instructions
-#define GLR_T4_STAGE(F, CC)                         \
-    __builtin_amdgcn_sched_barrier(0);              \
-    mma(F);                                         \
-    __builtin_amdgcn_sched_barrier(0);              \
-    if ((CC) < nch) load((CC), F);                  \
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int c = 0; c < nch; c += 3) {
-      GLR_T4_STAGE(f0, c + 3)
-      GLR_T4_STAGE(f1, c + 4)
-      GLR_T4_STAGE(f2, c + 5)
-    }
-#undef GLR_T4_STAGE
-  }
-
-  // ================= word-softmax statistics (as in the pair kernel; word block = t) =================
-  __syncthreads();
-  for (int i = tid; i < NS * SP; i += T4_NT) {
-    mx[i] = -INFINITY;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) ps[k * T4_MAXSEG * SP + i] = 0.f;
-  }
-  int sg0[4], sg1[4];
-#pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    sg0[g] = *reinterpret_cast<const int*>(wsegb + 4 * h + 8 * g);
-    sg1[g] = *reinterpret_cast<const int*>(wsegb + 32 + 4 * h + 8 * g);
-  }
-#define GLR_SGQ(pk, q) (((pk)[(q) >> 2] << (24 - 8 * ((q) & 3))) >> 24)
-  __syncthreads();
-  const int rbase = w * 32 + l31;
-  auto run_max = [&](f32x16 (&acc)[3], const int (&pk)[4]) {
-    float rm[3] = {-INFINITY, -INFINITY, -INFINITY};
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const int sg = GLR_SGQ(pk, q);
-      const bool last = (q == 15) || (GLR_SGQ(pk, (q + 1) & 15) != sg);
-#pragma unroll
-      for (int j = 0; j < 3; ++j) rm[j] = fmaxf(rm[j], acc[j][q]);
-      if (last && sg >= 0) {
-        float* dst = mx + sg * SP + rbase;
-#pragma unroll
-        for (int j = 0; j < 3; ++j)
-          __hip_atomic_fetch_max(dst + 128 * j, rm[j] * LOG2E, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      }
-#pragma unroll
-      for (int j = 0; j < 3; ++j) rm[j] = last ? -INFINITY : rm[j];
-    }
-  };
-  run_max(acc0, sg0);
-  run_max(acc1, sg1);
-  __syncthreads();
-  auto run_sum = [&](f32x16 (&acc)[3], const int (&pk)[4], int t) {
-    float* psw = ps + (t * 2 + h) * T4_MAXSEG * SP;
-    float rs[3] = {0.f, 0.f, 0.f};
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const int sg = GLR_SGQ(pk, q);
-      const bool last = (q == 15) || (GLR_SGQ(pk, (q + 1) & 15) != sg);
-      const float* src = mx + max(sg, 0) * SP + rbase;
-#pragma unroll
-      for (int j = 0; j < 3; ++j) rs[j] += __builtin_amdgcn_exp2f(__builtin_fmaf(acc[j][q], LOG2E, -src[128 * j]));
-      if (last && sg >= 0) {
-        float* dst = psw + sg * SP + rbase;
-#pragma unroll
-        for (int j = 0; j < 3; ++j) dst[128 * j] = rs[j];
-      }
-#pragma unroll
-      for (int j = 0; j < 3; ++j) rs[j] = last ? 0.f : rs[j];
-    }
-  };
-  run_sum(acc0, sg0, 0);
-  run_sum(acc1, sg1, 1);
-  __syncthreads();
-  for (int i = tid; i < NS * SP; i += T4_NT) {
-    const int s2 = i / SP, r = i - s2 * SP;
-    const float sum = (ps[i] + ps[T4_MAXSEG * SP + i]) + (ps[2 * T4_MAXSEG * SP + i] + ps[3 * T4_MAXSEG * SP + i]);
-    const float l2 = mx[i] + __builtin_amdgcn_logf(sum);
-    tab[i] = l2;
-    if (p.lse) p.lse[((size_t)b * p.n_sent + seg_sent[s2]) * SP + r] = l2 * LN2;
-  }
-  __syncthreads();
-
-  // ================= P2: e2 image, per-word Z and dot~ =================
-  const float t1l = p.temp1 * LOG2E;
-  const int rslot = w * 2 + ((lane >> 4) & 1);
-  float okr[3];
-#pragma unroll
-  for (int j = 0; j < 3; ++j) okr[j] = (rbase + 128 * j < p.S_eff) ? 1.f : 0.f;
-  auto p2 = [&](f32x16 (&acc)[3], const int (&pk)[4], int t) {
-    unsigned char* imgw = img + (t * 32 + 4 * h) * IMP + rbase * ESZ;
-    float* redt = red + rslot * TW + t * 32 + 4 * h;
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const int row = (q & 3) + 8 * (q >> 2);
-      const float* src = tab + max(GLR_SGQ(pk, q), 0) * SP + rbase;
-      float zacc = 0.f, dacc = 0.f;
-#pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        const float a1 = __builtin_amdgcn_exp2f(__builtin_fmaf(acc[j][q], LOG2E, -src[128 * j]));
-        const float e2 = __builtin_amdgcn_exp2f(t1l * a1);
-        O::from_f32(imgw + row * IMP + 128 * j * ESZ, e2);
-        const float e2r = bf2f(f2bf(e2));
-        zacc = __builtin_fmaf(e2r, okr[j], zacc);
-        dacc = __builtin_fmaf(e2r, acc[j][q], dacc);
-        acc[j][q] = 0.f;
-      }
-      const float z = row_sum16(zacc), d = row_sum16(dacc);
-      if ((lane & 15) == 15) {
-        redt[row] = z;
-        redt[8 * TW + row] = d;
-      }
-    }
-  };
-  // the image aliases the ps tables: every wave must be past its table reads (tab lives above)
-  p2(acc0, sg0, 0);
-  p2(acc1, sg1, 1);
-  __syncthreads();
-  if (tid < TW) {
-    float z = 0.f, d = 0.f;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) { z += red[k * TW + tid]; d += red[(8 + k) * TW + tid]; }
-    zsum[tid] = z;
-    dsum[tid] = d;
-  }
-
-  // ================= P3: acc = image . G^T, Gram rows straight from L2 =================
-  {
-    const unsigned char* b_base = gram_b + (size_t)w * 2048 + lane * 16;
-    const unsigned char* a_base = img + l31 * IMP + h * 16;
-    struct GF { bf16x8 b[2][3]; };
-    auto load = [&](int c, GF& f) {
-      const unsigned char* bc = b_base + (size_t)c * (SP * CHB);
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-        for (int j = 0; j < 3; ++j) f.b[kk][j] = O::ld(bc + (size_t)j * (4 * 2048) + kk * 1024);
-    };
-    auto mma = [&](int c, const GF& f) {
-      bf16x8 a0[2], a1[2];
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        a0[kk] = O::ld(a_base + c * CHB + kk * 32);
-        a1[kk] = O::ld(a_base + 32 * IMP + c * CHB + kk * 32);
-      }
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-          O::mma(a0[kk], f.b[kk][j], acc0[j]);
-          O::mma(a1[kk], f.b[kk][j], acc1[j]);
-        }
-    };
-    constexpr int nch = SP * ESZ / CHB;                            // 12
-    GF g0, g1, g2;
-    load(0, g0); load(1, g1); load(2, g2);
-#define GLR_T4_STAGE(C0, F, CC)                     \
-    __builtin_amdgcn_sched_barrier(0);              \
-    mma((C0), F);                                   \
-    __builtin_amdgcn_sched_barrier(0);              \
-    if ((CC) < nch) load((CC), F);                  \
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int c = 0; c < nch; c += 3) {
-      GLR_T4_STAGE(c, g0, c + 3)
-      GLR_T4_STAGE(c + 1, g1, c + 4)
-      GLR_T4_STAGE(c + 2, g2, c + 5)
-    }
-#undef GLR_T4_STAGE
-  }
-
-  // ================= P4 =================
-  auto p4 = [&](f32x16 (&acc)[3], int t) {
-    const unsigned char* imgw = img + (t * 32 + 4 * h) * IMP + rbase * ESZ;
-    float* redt = red + rslot * TW + t * 32 + 4 * h;
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const int row = (q & 3) + 8 * (q >> 2);
-      float v = 0.f;
-#pragma unroll
-      for (int j = 0; j < 3; ++j) v += O::to_f32(imgw + row * IMP + 128 * j * ESZ) * acc[j][q];
-      v = row_sum16(v);
-      if ((lane & 15) == 15) redt[row] = v;
-    }
-  };
-  __syncthreads();                    // zsum / dsum done with red
-  p4(acc0, 0);
-  p4(acc1, 1);
-  __syncthreads();
-  if (tid < TW) {
-    float nn = 0.f;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) nn += red[k * TW + tid];
-    const float z = zsum[tid], dd = dsum[tid];
-    float cosv = 0.f, nc2 = 0.f;
-    if (z > 0.f) {
-      const float iz = 1.f / z;
-      nc2 = fmaxf(nn, 0.f) * iz * iz;
-      const float den = fmaxf(tnl[tid] * sqrtf(nc2), p.eps);
-      cosv = dd * iz / den;
-    }
-    if (p.wstat) {
-      float* ws = p.wstat + ((size_t)b * p.n_slots + (size_t)tile * TW + tid) * WSTAT;
-      ws[0] = z; ws[1] = cosv; ws[2] = nc2; ws[3] = 0.f;
-    }
-    const int sg = wsegb[tid];
-    float v = __expf(p.temp2 * cosv);
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      const float o = __shfl_up(v, off, 64);
-      const int so = __shfl_up(sg, off, 64);
-      if (lane >= off && so == sg) v = (p.agg == GLR_AGG_MAX) ? fmaxf(v, o) : v + o;
-    }
-    const int snext = __shfl_down(sg, 1, 64);
-    if (sg >= 0 && (lane == 63 || snext != sg)) {
-      if (p.agg == GLR_AGG_MEAN) v /= (float)seg_n[sg];
-      p.sim[(size_t)b * p.ld_sim + seg_sent[sg]] = p.temp3 * __logf(v);
-    }
-  }
-  const int dw0 = misc[1], dn = misc[2];
-  if (p.attn != nullptr && dn > 0) {
-    const int sout = p.S_eff - p.strip;
-    float* out = p.attn + p.attn_off[p.img_offset + b];
-    for (int idx = tid; idx < dn * sout; idx += T4_NT) {
-      const int wq = idx / sout, r = idx % sout + p.strip;
-      out[idx] = O::to_f32(img + (dw0 + wq) * IMP + r * ESZ) / zsum[dw0 + wq];
-    }
-  }
-  if (p.amean != nullptr) {
-    for (int r = tid; r < SP; r += T4_NT)
-      for (int s2 = 0; s2 < NS; ++s2) {
-        const int w0 = seg_w0[s2], n = seg_n[s2];
-        float a = 0.f;
-        for (int k = 0; k < n; ++k) a += O::to_f32(img + (w0 + k) * IMP + r * ESZ) / zsum[w0 + k];
-        p.amean[((size_t)b * p.n_sent + seg_sent[s2]) * SP + r] = r < p.S_eff ? a / (float)n : 0.f;
-      }
-  }
-#undef GLR_SGQ
-}
-
-const unsigned char *g_t4_vt = nullptr, *g_t4_gram = nullptr, *g_t4_tp = nullptr;   // fragment-major operands (experimental)
 
 #ifdef GLR_STAMPS
 unsigned long long* g_stamps = nullptr;
@@ -1572,15 +1293,14 @@ int carve(LaParams& p, int op_dtype, int S_pad) {
   return p.off_small + 12288;
 }
 
-// pair kernel: [0, 2*IMG) images (earlier: P1 ring, mx / ps tables) | lse tables, then the 2-deep P3 ring | small
+// pair kernel: [0, 2*IMG) images (earlier: P1 ring) | statistics tables, then the 2-deep P3 ring | small
 int carve_pair(LaParams& p, int op_dtype, int S_pad) {
   const int esz = op_dtype == GLR_F32 ? 4 : 2;
   const int img_bytes = TW * (GLR_MAX_SPAD * esz + 16);
-  const int tab_bytes = 2 * PAIR_MAXSEG * S_pad * 4;          // lse table + segment maxima
-  const int walk_bytes = 4 * PAIR_MAXSEG * GLR_MAX_SPAD * 4;  // partial-sum tables (alias the images)
+  const int tab_bytes = 4 * PW_MAXSEG * S_pad * 4;            // maxima + sums, one table per lane half
   const int ring3 = 2 * S_pad * CHB;
   const int ring1 = NBUF * (2 * p.tw + S_pad) * CHB;
-  p.off_img = max(2 * img_bytes, walk_bytes);      // tables / P3 ring
+  p.off_img = 2 * img_bytes;                       // tables / P3 ring
   p.off_small = max(p.off_img + max(tab_bytes, ring3), ring1);
   return p.off_small + 12288;
 }
@@ -1619,7 +1339,7 @@ int launch(LaParams& p, int op_dtype, void* stream) {
 
 int launch_pair(LaParams& p, int op_dtype, void* stream) {
   if (op_dtype != GLR_BF16) return GLR_EINVAL;      // the fp32 mode (32-word tiles) is never paired
-  if (p.S_pad != GLR_MAX_SPAD) return GLR_EINVAL;   // the pair kernel is built for the 384-region shape only
+  if (p.S_pad != GLR_MAX_SPAD) return GLR_EINVAL;   // the pair kernels are built for the 384-region shape only
   const int lds = carve_pair(p, op_dtype, p.S_pad);
   if (lds > 160 * 1024) return GLR_EINVAL;
   // images per XCD rounded up to a multiple of the L2 group size
@@ -1627,29 +1347,14 @@ int launch_pair(LaParams& p, int op_dtype, void* stream) {
   p.img_block = env_ib > 0 ? env_ib : 4;
   const int per_xcd = ((p.B_img + 7) / 8 + p.img_block - 1) / p.img_block * p.img_block;
   const int grid = per_xcd * 8 * p.n_items;
-  static const bool env_t4 = [] { const char* e = getenv("GLR_K1_T4"); return e && atoi(e) == 1; }();
-  const bool use_t4 = env_t4 && p.D == 768 && g_t4_vt && g_t4_gram && g_t4_tp;
-  p.t4 = use_t4 ? 1 : 0;
-  p.vt_f = g_t4_vt; p.gram_f = g_t4_gram; p.tp_f = g_t4_tp;
-  if (hipFuncSetAttribute((const void*)k_local_attn_pair<OpBF16>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return GLR_ELAUNCH;
-  hipLaunchKernelGGL((k_local_attn_pair<OpBF16>), dim3(grid), dim3(NTHR), lds, (hipStream_t)stream, p);
+  // the pair kernel needs the planner's row flags and a spare padded region for the ones row of the Gram operand
+  if (p.rowflags == nullptr || p.S_eff >= p.S_pad) return GLR_EINVAL;
+#ifdef GLR_ABLATE
+  { const char* e = getenv("GLR_K1_DBG"); p.dbg = e ? atoi(e) : 0; }
+#endif
+  if (hipFuncSetAttribute((const void*)k_local_attn_pw<OpBF16>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return GLR_ELAUNCH;
+  hipLaunchKernelGGL((k_local_attn_pw<OpBF16>), dim3(grid), dim3(NTHR), lds, (hipStream_t)stream, p);
   GLR_CHECK_LAUNCH();
-  if (use_t4) {
-    // [0, 60 KiB) tables / image | lse table | small
-    // GLR_K1_T4_PAD (diagnostic): extra LDS bytes, e.g. 8192 forces ONE workgroup per CU
-    static const int env_pad = [] { const char* e = getenv("GLR_K1_T4_PAD"); return e ? atoi(e) : 0; }();
-    const int lds4 = (4 + 1 + 1) * T4_MAXSEG * GLR_MAX_SPAD * 4 + 6144 + env_pad;
-    static bool said = false;
-    if (!said && getenv("GLR_K1_T4_VERBOSE")) {
-      int nb = 0;
-      (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)k_local_attn_t4, T4_NT, lds4);
-      fprintf(stderr, "[glr] k_local_attn_t4: %d bytes of LDS, %d workgroups per CU\n", lds4, nb);
-      said = true;
-    }
-    if (hipFuncSetAttribute((const void*)k_local_attn_t4, hipFuncAttributeMaxDynamicSharedMemorySize, lds4) != hipSuccess) return GLR_ELAUNCH;
-    hipLaunchKernelGGL(k_local_attn_t4, dim3(2 * grid), dim3(T4_NT), lds4, (hipStream_t)stream, p);
-    GLR_CHECK_LAUNCH();
-  }
   return GLR_OK;
 }
 
@@ -1665,7 +1370,7 @@ int fill_common(LaParams& p, const void* vt, const void* gram, const void* tp, c
   if (agg < 0 || agg > 2) return GLR_EINVAL;
   p.vt = (const unsigned char*)vt; p.gram = (const unsigned char*)gram; p.tp = (const unsigned char*)tp;
   p.tnorm = tnorm; p.sent_slot0 = sent_slot0; p.cap_lens = cap_lens; p.tile_first = tile_first; p.order = order;
-  p.tile_nsub = tile_nsub; p.item_tile = nullptr; p.n_items = 0; p.amean = nullptr; p.damean = nullptr; p.dattn = nullptr; p.t4 = 0; p.n_tiles = n_tiles; p.n_sent = n_sent;
+  p.tile_nsub = tile_nsub; p.item_tile = nullptr; p.n_items = 0; p.amean = nullptr; p.damean = nullptr; p.dattn = nullptr; p.rowflags = nullptr; p.n_tiles = n_tiles; p.n_sent = n_sent;
   p.n_slots = n_tiles * TW; p.B_img = B_img;
   p.D = D; p.S_eff = S_eff; p.S_pad = S_pad; p.temp1 = temp1; p.temp2 = temp2; p.temp3 = temp3; p.agg = agg;
   p.eps = eps;
@@ -1682,15 +1387,11 @@ int fill_common(LaParams& p, const void* vt, const void* gram, const void* tp, c
 
 }  // namespace
 
-extern "C" int glr_set_t4_operands(const void* vt_f, const void* gram_f, const void* tp_f) {
-  g_t4_vt = (const unsigned char*)vt_f; g_t4_gram = (const unsigned char*)gram_f; g_t4_tp = (const unsigned char*)tp_f;
-  return GLR_OK;
-}
-
 extern "C" int glr_local_attn_fwd(const void* vt, const void* gram, const void* tp, const float* tnorm,
                                   const int32_t* sent_slot0, const int32_t* cap_lens,
                                   const int32_t* tile_first, const int32_t* order, const int32_t* tile_nsub,
                                   const int32_t* single_tile, int n_single, const int32_t* pair_tile, int n_pair,
+                                  const uint32_t* tile_rowflags,
                                   int n_tiles, int n_sent, int B_img, int D, int S_eff, float temp1, float temp2,
                                   float temp3, int agg, float eps, float* sim, int ld_sim, float* lse, float* wstat,
                                   float* attn, const int64_t* attn_off, int strip, int pair_only, int img_offset,
@@ -1712,7 +1413,7 @@ extern "C" int glr_local_attn_fwd(const void* vt, const void* gram, const void* 
     if (rc != GLR_OK) return rc;
   }
   if (!pair_only && n_pair > 0) {
-    p.item_tile = pair_tile; p.n_items = n_pair;
+    p.item_tile = pair_tile; p.n_items = n_pair; p.rowflags = tile_rowflags;
     rc = launch_pair(p, op_dtype, stream);
   }
   return rc;

@@ -11,7 +11,7 @@
 
 #include "glr_common.h"
 
-extern "C" int glr_version(void) { return 1; }
+extern "C" int glr_version(void) { return 2; }
 
 extern "C" int glr_plan_tiles_bound(const int32_t* cap_lens, int n_sent, int capacity) {
   if (!cap_lens || n_sent <= 0 || (capacity != 32 && capacity != GLR_TILE_WORDS)) return GLR_EINVAL;
@@ -83,6 +83,59 @@ extern "C" int glr_plan_items(const int32_t* tile_nsub, const int32_t* tile_firs
     }
   }
   counts[0] = ns; counts[1] = np; counts[2] = na;
+  return GLR_OK;
+}
+
+// Row flags of the forward pair kernel.  There a wave holds ALL 64 word slots of a tile for its region columns:
+// lane half h (lane >> 5) owns the slots w with ((w >> 2) & 1) == h, 32 rows in word order, row index
+// k(w) = 16 (w >> 5) + 4 ((w & 31) >> 3) + (w & 3) (the accumulator register, second 32-word block at k >= 16).
+// The words of a sentence are a run of rows in each half; the kernel walks the rows once per pass and only acts
+// where a run starts or ends, which is the same for all lanes of a half: per tile and half one bit per row.
+//   flags[tile][0..1]  START bits of half 0 / 1: first row of a sentence's run
+//   flags[tile][2..3]  LAST  bits: last row of a run
+//   flags[tile][4..5]  OWNER bits (subset of START): the run that holds the sentence's first word (that lane half
+//                      stores the sentence's log-sum-exp row for the backward pass)
+//   flags[tile][6..7]  reserved (0)
+extern "C" int glr_plan_rowflags(const int32_t* cap_lens, const int32_t* sent_slot0, const int32_t* tile_first,
+                                 const int32_t* order, const int32_t* tile_nsub, int n_tiles, int capacity,
+                                 uint32_t* flags) {
+  if (!cap_lens || !sent_slot0 || !tile_first || !order || !tile_nsub || !flags || n_tiles <= 0) return GLR_EINVAL;
+  if (capacity != GLR_TILE_WORDS) return GLR_EINVAL;          // the pair kernel runs full-width (bf16) tiles only
+  memset(flags, 0, sizeof(uint32_t) * 8 * (size_t)n_tiles);
+  auto row_of = [](int w) { return 16 * (w >> 5) + 4 * ((w & 31) >> 3) + (w & 3); };
+  int head = 0;                                               // head tile of the current multi-tile sentence
+  for (int t = 0; t < n_tiles; ++t) {
+    if (tile_nsub[t] >= 0) head = t;
+    uint32_t* f = flags + 8 * (size_t)t;
+    for (int k = tile_first[t]; k < tile_first[t + 1]; ++k) {
+      const int sent = order[k];
+      int a, e;
+      bool owner = true;
+      if (tile_nsub[t] == 0) {
+        a = sent_slot0[sent] - t * GLR_TILE_WORDS;
+        e = a + cap_lens[sent];
+      } else {                                                // tile (t - head) of a sentence that owns whole tiles
+        const int sub = t - head;
+        a = 0;
+        e = cap_lens[sent] - sub * capacity;
+        if (e > capacity) e = capacity;
+        owner = sub == 0;
+      }
+      if (a < 0 || e > GLR_TILE_WORDS || e <= a) return GLR_EINVAL;
+      int first[2] = {-1, -1}, last[2] = {-1, -1};
+      for (int w = a; w < e; ++w) {
+        const int hh = (w >> 2) & 1;
+        if (first[hh] < 0) first[hh] = w;
+        last[hh] = w;
+      }
+      for (int hh = 0; hh < 2; ++hh) {
+        if (first[hh] < 0) continue;
+        f[hh] |= 1u << row_of(first[hh]);
+        f[2 + hh] |= 1u << row_of(last[hh]);
+        if (owner && first[hh] == a) f[4 + hh] |= 1u << row_of(first[hh]);
+      }
+    }
+  }
   return GLR_OK;
 }
 
@@ -180,34 +233,7 @@ __global__ void k_tile_k(const uint4* __restrict__ src, uint4* __restrict__ dst,
   dst[i] = src[((blk * rows + r) * nch + c) * 4 + s16];
 }
 
-// Fragment-major packing (experimental k_local_attn_t4): every MFMA operand fragment - 32 rows x 32 bytes of K, i.e.
-// the 16 bytes each of the 64 lanes feeds to one v_mfma_f32_32x32x16_bf16 - is stored as 1 KiB contiguous in lane
-// order: [block][K chunk of 64 B][32-row block][k-step of the chunk][lane][16 B].
-__global__ void k_tile_frag(const uint4* __restrict__ src, uint4* __restrict__ dst, int rows, int nch, size_t total) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= total) return;
-  const int lane = (int)(i & 63);
-  size_t f = i >> 6;
-  const int kk = (int)(f & 1); f >>= 1;
-  const int nrb = rows / 32;
-  const int rb = (int)(f % nrb); f /= nrb;
-  const int c = (int)(f % nch);
-  const size_t blk = f / nch;
-  const int row = rb * 32 + (lane & 31);
-  const int piece = c * 4 + kk * 2 + (lane >> 5);              // 16-byte piece inside the row
-  dst[i] = src[(blk * rows + row) * (size_t)(nch * 4) + piece];
-}
-
 }  // namespace
-
-extern "C" int glr_tile_frag(const void* src, void* dst, int rows, long long n_blocks, int row_bytes, void* stream) {
-  if (!src || !dst || rows <= 0 || rows % 32 != 0 || n_blocks <= 0 || row_bytes <= 0 || row_bytes % 64 != 0) return GLR_EINVAL;
-  const size_t total = (size_t)n_blocks * rows * (row_bytes / 16);
-  hipLaunchKernelGGL(k_tile_frag, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                     (const uint4*)src, (uint4*)dst, rows, row_bytes / 64, total);
-  GLR_CHECK_LAUNCH();
-  return GLR_OK;
-}
 
 extern "C" int glr_tile_k(const void* src, void* dst, int rows, long long n_blocks, int row_bytes, void* stream) {
   if (!src || !dst || rows <= 0 || n_blocks <= 0 || row_bytes <= 0 || row_bytes % 64 != 0) return GLR_EINVAL;

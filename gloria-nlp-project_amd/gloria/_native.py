@@ -27,13 +27,12 @@ SYMBOLS = {
     "glr_plan_tiles_bound": (c_int, [c_void_p, c_int, c_int]),
     "glr_plan_tiles": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "glr_plan_items": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "glr_plan_rowflags": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "glr_tile_k": (c_int, [c_void_p, c_void_p, c_int, ctypes.c_longlong, c_int, c_void_p]),
-    "glr_tile_frag": (c_int, [c_void_p, c_void_p, c_int, ctypes.c_longlong, c_int, c_void_p]),
-    "glr_set_t4_operands": (c_int, [c_void_p, c_void_p, c_void_p]),
     "glr_pack_regions": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "glr_pack_words": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                c_int, c_int, c_int, c_void_p]),
-    "glr_local_attn_fwd": (c_int, [c_void_p] * 10 + [c_int, c_void_p] + [c_int] * 6 + [c_float] * 3 + [c_int, c_float, c_void_p, c_int,
+    "glr_local_attn_fwd": (c_int, [c_void_p] * 10 + [c_int, c_void_p, c_int, c_void_p] + [c_int] * 5 + [c_float] * 3 + [c_int, c_float, c_void_p, c_int,
                                    c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
                                    # ..., sim, ld, lse, wstat, attn, attn_off, strip, pair_only, img_offset, amean, dtype, stream
     "glr_local_attn_bwd": (c_int, [c_void_p] * 10 + [c_int] * 6 + [c_float] * 3 + [c_int, c_float, c_void_p, c_void_p,
@@ -55,7 +54,7 @@ SYMBOLS = {
     "glr_dual_ce_bwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "glr_global_sim_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float, c_void_p, c_int,
                                    c_void_p, c_void_p, c_void_p]),
-    "glr_global_sim_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+    "glr_global_sim_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                    c_float, c_float, c_void_p, c_void_p, c_void_p]),
     "glr_wordpiece_segsum_fwd": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                          c_int, c_void_p]),
@@ -142,19 +141,28 @@ class TilePlan:
         alls = np.zeros(nt, dtype=np.int32)
         counts = np.zeros(3, dtype=np.int32)
         rc = L.glr_plan_items(nsub.ctypes.data_as(c_void_p), tile_first.ctypes.data_as(c_void_p), nt,
-                              1 if (allow_pairs and capacity == TILE_WORDS) else 0, 16,
+                              1 if (allow_pairs and capacity == TILE_WORDS) else 0, 8,
                               singles.ctypes.data_as(c_void_p), pairs.ctypes.data_as(c_void_p),
                               alls.ctypes.data_as(c_void_p), counts.ctypes.data_as(c_void_p))
         if rc != 0:
             raise ValueError(f"glr_plan_items failed ({rc})")
         self.n_single, self.n_pair, self.n_all = (int(c) for c in counts)
+        # run boundaries per tile and lane half for the forward pair kernel (full-width tiles only)
+        flags = np.zeros(nt * 8, dtype=np.uint32)
+        if self.n_pair:
+            rc = L.glr_plan_rowflags(cl.ctypes.data_as(c_void_p), slot0.ctypes.data_as(c_void_p),
+                                     tile_first.ctypes.data_as(c_void_p), order.ctypes.data_as(c_void_p),
+                                     nsub.ctypes.data_as(c_void_p), nt, capacity, flags.ctypes.data_as(c_void_p))
+            if rc != 0:
+                raise ValueError(f"glr_plan_rowflags failed ({rc})")
+        self.rowflags_host = flags.reshape(nt, 8)
         self.capacity = capacity
         self.cap_lens_host = cl
         self.n_sent, self.n_tiles, self.n_slots = n, nt, nt * TILE_WORDS
         self.sent_slot0_host = slot0
         self.n_words = int(cl.sum())
         pack = np.concatenate([cl, slot0, tile_first[: nt + 1], order, nsub[:nt], singles[:self.n_single],
-                               pairs[:self.n_pair], alls[:self.n_all]]).astype(np.int32)
+                               pairs[:self.n_pair], alls[:self.n_all], flags.view(np.int32)]).astype(np.int32)
         dev = torch.from_numpy(pack).to(device, non_blocking=True)
         o = 0
         self.cap_lens = dev[o:o + n]; o += n
@@ -164,7 +172,8 @@ class TilePlan:
         self.tile_nsub = dev[o:o + nt]; o += nt
         self.single_tile = dev[o:o + self.n_single]; o += self.n_single
         self.pair_tile = dev[o:o + self.n_pair]; o += self.n_pair
-        self.all_tile = dev[o:o + self.n_all]
+        self.all_tile = dev[o:o + self.n_all]; o += self.n_all
+        self.rowflags = dev[o:o + nt * 8] if self.n_pair else None
         self._dev = dev
         self._word_index = None
 

@@ -23,11 +23,33 @@ import torch
 from .. import _native as N
 from . import _recompute as R
 
-import os
-
-_T4 = os.environ.get("GLR_K1_T4", "0") == "1"      # experimental K1 forward kernel
 _COMPUTE_DTYPE = None          # None = follow the input dtype
-K1_EVENTS = None               # bench.py sets this to a list to collect (start, end, flops) of every K1 launch
+# bench.py sets this to {} to collect HIP events on the launch stream (the stream torch's events record on is the
+# stream libglr launches on: N.stream()).  Keys -> lists of (event, event):
+#   "k1_fwd"     the K1 forward launches alone               "k1_fwd_op"  packing + Gram + tiling + K1 forward
+#   "k1_bwd"     the K1 backward launch alone                "k1_bwd_op"  K1 backward + gradient GEMMs + scatter
+# and "k1_flops": algorithmic forward FLOPs of every forward call.
+PROFILE = None
+
+
+class _Range:
+    """event pair around a region of the current stream, recorded only while PROFILE is a dict"""
+
+    def __init__(self, key):
+        self.key, self.on = key, PROFILE is not None
+
+    def __enter__(self):
+        if self.on:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        return self
+
+    def __exit__(self, *a):
+        if self.on:
+            self.e1.record()
+            PROFILE.setdefault(self.key, []).append((self.e0, self.e1))
+        return False
 
 
 def set_compute_dtype(dtype: Optional[torch.dtype]):
@@ -78,7 +100,7 @@ def _pack_operands(img_features, words, no_attn_vec, cap_lens, o):
         raise ValueError(f"embedding dim must be a multiple of 64, got {D}")
     code = _op_code(img_features, words)
     odt = N.torch_dtype(code)
-    plan = N.TilePlan(cap_lens, dev, L.glr_tile_capacity(code), allow_pairs=(s_pad == N.MAX_SPAD))
+    plan = N.TilePlan(cap_lens, dev, L.glr_tile_capacity(code), allow_pairs=(s_pad == N.MAX_SPAD and s_eff < s_pad))
     # channels-last feature maps already are [B, S, D] in memory: no transpose needed
     img = img_features
     layout = 0
@@ -96,6 +118,10 @@ def _pack_operands(img_features, words, no_attn_vec, cap_lens, o):
     N.check(L.glr_pack_regions(N.ptr(img), in_code, layout, N.ptr(na), N.ptr(vt), B, D, S, code, st),
             "glr_pack_regions")
     gram = torch.bmm(vt, vt.transpose(1, 2))            # plain batched GEMM (hipBLASLt): G[b] = V^T V
+    if s_eff < s_pad:
+        # ones in a padded row: the forward pair kernel reads Z_w = sum_r e2[w, r] out of the second contraction
+        # (include/glr.h, tile_rowflags); every kernel masks padded regions, so nothing else sees the row
+        gram[:, s_pad - 1, :s_eff] = 1.0
     tp = torch.empty(plan.n_slots, D, dtype=odt, device=dev)
     tnorm = torch.empty(plan.n_slots, dtype=torch.float32, device=dev)
     N.check(L.glr_pack_words(N.ptr(words), in_code, N.ptr(plan.sent_slot0), N.ptr(plan.cap_lens), N.ptr(tp),
@@ -107,16 +133,6 @@ def _pack_operands(img_features, words, no_attn_vec, cap_lens, o):
     N.check(L.glr_tile_k(N.ptr(vt), N.ptr(vt_t), s_pad, B, D * esz, st), "glr_tile_k")
     N.check(L.glr_tile_k(N.ptr(gram), N.ptr(gram_t), s_pad, B, s_pad * esz, st), "glr_tile_k")
     N.check(L.glr_tile_k(N.ptr(tp), N.ptr(tp_t), N.TILE_WORDS, plan.n_tiles, D * esz, st), "glr_tile_k")
-    if _T4 and code == N.GLR_BF16 and s_pad == N.MAX_SPAD and D == 768:
-        # experimental forward kernel (GLR_K1_T4=1): fragment-major copies of the three operands
-        keep = [torch.empty_like(vt), torch.empty_like(gram), torch.empty_like(tp)]
-        N.check(L.glr_tile_frag(N.ptr(vt), N.ptr(keep[0]), s_pad, B, D * esz, st), "glr_tile_frag")
-        N.check(L.glr_tile_frag(N.ptr(gram), N.ptr(keep[1]), s_pad, B, s_pad * esz, st), "glr_tile_frag")
-        N.check(L.glr_tile_frag(N.ptr(tp), N.ptr(keep[2]), N.TILE_WORDS, plan.n_tiles, D * esz, st), "glr_tile_frag")
-        L.glr_set_t4_operands(N.ptr(keep[0]), N.ptr(keep[1]), N.ptr(keep[2]))
-        plan._t4_keep = keep                     # alive until the forward launch has been queued (same stream)
-    elif _T4:
-        L.glr_set_t4_operands(None, None, None)
     return plan, code, vt, vt_t, gram_t, tp, tp_t, tnorm, s_eff, s_pad, shift
 
 
@@ -127,7 +143,7 @@ def _k1_args(plan, vt, gram, tp, tnorm, B, D, s_eff, o, backward=False):
         items = (N.ptr(plan.all_tile), plan.n_all)
     else:
         items = (N.ptr(plan.single_tile) if plan.n_single else None, plan.n_single,
-                 N.ptr(plan.pair_tile) if plan.n_pair else None, plan.n_pair)
+                 N.ptr(plan.pair_tile) if plan.n_pair else None, plan.n_pair, N.ptr(plan.rowflags))
     return head + items + (plan.n_tiles, plan.n_sent, B, D, s_eff, o.temp1, o.temp2, o.temp3, N.AGG[o.agg], o.eps)
 
 
@@ -146,6 +162,8 @@ class LocalSimFn(torch.autograd.Function):
         img = _as_supported(img_features.detach()) if img_features.dtype not in (torch.float32, torch.bfloat16) \
             else img_features.detach()
         words = _as_supported(words_emb.detach())
+        op_range = _Range("k1_fwd_op")
+        op_range.__enter__()
         plan, code, vt, vt_t, gram_t, tp, tp_t, tnorm, s_eff, s_pad, shift = _pack_operands(img, words, no_attn_vec, cap_lens, o)
         dev = img.device
         B, D = img.shape[:2]
@@ -160,18 +178,16 @@ class LocalSimFn(torch.autograd.Function):
         if o.want_attn:
             attn_off, off_host = plan.attn_offsets(s_eff - strip, dev)
             attn = torch.zeros(int(off_host[-1]), dtype=torch.float32, device=dev)
-        if K1_EVENTS is not None:
-            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            ev0.record()
         amean = torch.empty(B, n_sent, s_pad, dtype=torch.float32, device=dev) if o.want_amean else None
-        N.check(L.glr_local_attn_fwd(*_k1_args(plan, vt_t, gram_t, tp_t, tnorm, B, D, s_eff, o), N.ptr(sim), n_sent,
-                                     N.ptr(lse), N.ptr(wstat), N.ptr(attn), N.ptr(attn_off), strip,
-                                     1 if o.pair_only else 0, o.img_offset, N.ptr(amean), code, N.stream()),
-                "glr_local_attn_fwd")
-        if K1_EVENTS is not None:
-            ev1.record()
+        with _Range("k1_fwd"):
+            N.check(L.glr_local_attn_fwd(*_k1_args(plan, vt_t, gram_t, tp_t, tnorm, B, D, s_eff, o), N.ptr(sim), n_sent,
+                                         N.ptr(lse), N.ptr(wstat), N.ptr(attn), N.ptr(attn_off), strip,
+                                         1 if o.pair_only else 0, o.img_offset, N.ptr(amean), code, N.stream()),
+                    "glr_local_attn_fwd")
+        op_range.__exit__()
+        if PROFILE is not None:
             n_words = plan.n_words if not o.pair_only else plan.n_words // max(n_sent, 1)
-            K1_EVENTS.append((ev0, ev1, (4.0 * s_eff * D + 6.0 * D) * B * n_words))
+            PROFILE.setdefault("k1_flops", []).append((4.0 * s_eff * D + 6.0 * D) * B * n_words)
         wctx = None
         if o.want_wctx:      # attention_fn's first output: V . a2^T for the B diagonal pairs (plain bmm)
             n = int(plan.cap_lens_host[0])
@@ -223,10 +239,13 @@ class LocalSimFn(torch.autograd.Function):
             gamma = torch.empty(B, ns, dtype=torch.float32, device=dev)
             beta = torch.empty(B, ns, dtype=torch.float32, device=dev)
             g = dsim.float().contiguous()
-            N.check(L.glr_local_attn_bwd(*_k1_args(plan, vt_t, gram_t, tp_t, tnorm, B, D, s_eff, o, True), N.ptr(sim), N.ptr(g),
-                                         plan.n_sent, N.ptr(lse), N.ptr(wstat), N.ptr(dam), N.ptr(dat), N.ptr(dat_off),
-                                         strip, o.img_offset, N.ptr(xout), N.ptr(aout),
-                                         N.ptr(gamma), N.ptr(beta), code, N.stream()), "glr_local_attn_bwd")
+            bwd_range = _Range("k1_bwd_op")
+            bwd_range.__enter__()
+            with _Range("k1_bwd"):
+                N.check(L.glr_local_attn_bwd(*_k1_args(plan, vt_t, gram_t, tp_t, tnorm, B, D, s_eff, o, True), N.ptr(sim),
+                                             N.ptr(g), plan.n_sent, N.ptr(lse), N.ptr(wstat), N.ptr(dam), N.ptr(dat),
+                                             N.ptr(dat_off), strip, o.img_offset, N.ptr(xout), N.ptr(aout),
+                                             N.ptr(gamma), N.ptr(beta), code, N.stream()), "glr_local_attn_bwd")
             # gradient GEMMs (plain library GEMMs on the kernel's outputs)
             x2d = xout.view(ns, B * s_pad)
             dtp = (x2d @ vt.view(B * s_pad, D)).float() - gamma.sum(0).unsqueeze(1) * tp.float()      # [ns, D]
@@ -237,6 +256,7 @@ class LocalSimFn(torch.autograd.Function):
             d_img += dvt[:, shift:s_eff].transpose(1, 2)
             if d_na is not None:
                 d_na += dvt[:, 0].sum(0)
+            bwd_range.__exit__()
 
         need_attn = need_attn and not hip_attn
         if need_attn or need_wctx:
@@ -322,18 +342,18 @@ class GlobalSimFn(torch.autograd.Function):
         nt = torch.empty(Bt, dtype=torch.float32, device=a.device)
         N.check(L.glr_global_sim_fwd(N.ptr(a), N.ptr(t), Bi, Bt, D, float(temp3), float(eps), N.ptr(sim), Bt,
                                      N.ptr(ni), N.ptr(nt), N.stream()), "glr_global_sim_fwd")
-        ctx.save_for_backward(a, t, ni, nt)
+        ctx.save_for_backward(a, t, ni, nt, sim)
         ctx.temp3, ctx.eps, ctx.dt = float(temp3), float(eps), (img.dtype, txt.dtype)
         return sim
 
     @staticmethod
     def backward(ctx, dsim):
-        a, t, ni, nt = ctx.saved_tensors
+        a, t, ni, nt, sim = ctx.saved_tensors
         Bi, D = a.shape
         Bt = t.shape[0]
         d = dsim.float().contiguous()
         da, dt_ = torch.empty_like(a), torch.empty_like(t)
-        N.check(N.lib().glr_global_sim_bwd(N.ptr(a), N.ptr(t), N.ptr(ni), N.ptr(nt), N.ptr(d), Bt, Bi, Bt, D,
+        N.check(N.lib().glr_global_sim_bwd(N.ptr(a), N.ptr(t), N.ptr(ni), N.ptr(nt), N.ptr(sim), N.ptr(d), Bt, Bi, Bt, D,
                                            ctx.temp3, ctx.eps, N.ptr(da), N.ptr(dt_), N.stream()),
                 "glr_global_sim_bwd")
         return da.to(ctx.dt[0]), dt_.to(ctx.dt[1]), None, None

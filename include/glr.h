@@ -13,7 +13,7 @@
  *     freed or synchronised inside; work is enqueued on `stream` and the call returns.
  *     Workspace is caller-provided; sizes come from the *_bytes queries.
  *   - return 0 on success, a negative GLR_E* code on error (bad shape / unsupported dtype /
- *     launch failure).  No global mutable state: calls are thread safe.
+ *     launch failure).  No global mutable state: calls are thread safe (every operand travels as an argument).
  *   - dtype codes: GLR_F32 = 0 (fp32 operands, fp32 MFMA, the 1e-4 parity mode),
  *                  GLR_BF16 = 1 (bf16 operands, fp32 accumulate / softmax / log / exp).
  *   - region features are `[B, D, S]` (NCHW with H*W = S flattened, region contiguous), word
@@ -83,7 +83,7 @@ int glr_plan_tiles(const int32_t* cap_lens, int n_sent, int capacity, int32_t* s
                    int32_t* tile_first, int32_t* order, int32_t* tile_nsub);
 
 /* Work items of the local-attention kernels.  With allow_pairs, two consecutive ordinary tiles that hold
- * at most max_pair_seg (16) sentences IN TOTAL become ONE forward work item: a workgroup then streams vt[b] and
+ * at most max_pair_seg (<= 8) sentences IN TOTAL become ONE forward work item: a workgroup then streams vt[b] and
  * gram[b] once for 128 words (the streams are the bound).  Outputs (each must hold n_tiles ints):
  *   single_tile  first tile of every un-paired item (ordinary tile or head of a multi-tile sentence)
  *   pair_tile    first tile of every pair: two ordinary tiles, or the two tiles owned by ONE sentence of 65..128 words
@@ -92,6 +92,15 @@ int glr_plan_tiles(const int32_t* cap_lens, int n_sent, int capacity, int32_t* s
  */
 int glr_plan_items(const int32_t* tile_nsub, const int32_t* tile_first, int n_tiles, int allow_pairs,
                    int max_pair_seg, int32_t* single_tile, int32_t* pair_tile, int32_t* all_tile, int32_t* counts);
+
+/* Row flags of the forward pair kernel (host).  In that kernel one wave holds all 64 word slots of a tile for its
+ * region columns, 32 rows per lane half in word order; a sentence is a run of rows, and the kernel acts only where
+ * a run starts or ends.  flags[n_tiles][8] (uint32, bit k = row k of the lane half): [0..1] run starts of half
+ * 0 / 1, [2..3] run ends, [4..5] the run holding the sentence's first word, [6..7] reserved.  Replaces the
+ * per-sentence slice boundaries of the reference loop (gloria_loss.py:122) inside a packed tile.  capacity must be
+ * GLR_TILE_WORDS. */
+int glr_plan_rowflags(const int32_t* cap_lens, const int32_t* sent_slot0, const int32_t* tile_first,
+                      const int32_t* order, const int32_t* tile_nsub, int n_tiles, int capacity, uint32_t* flags);
 
 /* ------------------------------------------------------------------------------------------
  * Operand packing (device).  HBM-bound layout/convert kernels.
@@ -135,6 +144,11 @@ int glr_pack_words(const void* words_emb, int in_dtype, const int32_t* sent_slot
  *   tile_first, order, tile_nsub   device int32 copies of the glr_plan_tiles outputs
  *   single_tile/n_single, pair_tile/n_pair (fwd), item_tile/n_items (bwd: the all_tile list)
  *                device int32 copies of the glr_plan_items outputs
+ *   tile_rowflags  (fwd) device copy of the glr_plan_rowflags output [n_tiles][8], or NULL.  With it, and with
+ *                S_eff < S_pad, pairs run the wave-owned-words kernel, which also expects gram[b] to carry ONES in
+ *                row S_pad - 1, columns r < S_eff (a padded region): the second contraction then delivers
+ *                Z_w = sum_r e2[w, r] in output column S_pad - 1.  Every other kernel masks padded regions, so
+ *                the same gram serves them and the backward.
  *   sim          fp32 [B_img, ld_sim]; column = sentence id (fwd: out, bwd: in)
  *   lse          fp32 [B_img, n_sent, S_pad]: log-sum-exp over the words of sentence i of the
  *                scores of region r (fwd: optional out, needed by bwd)
@@ -164,10 +178,10 @@ int glr_pack_words(const void* words_emb, int in_dtype, const int32_t* sent_slot
 int glr_local_attn_fwd(const void* vt, const void* gram, const void* tp, const float* tnorm,
                        const int32_t* sent_slot0, const int32_t* cap_lens, const int32_t* tile_first,
                        const int32_t* order, const int32_t* tile_nsub, const int32_t* single_tile, int n_single,
-                       const int32_t* pair_tile, int n_pair, int n_tiles, int n_sent, int B_img, int D, int S_eff,
-                       float temp1, float temp2, float temp3, int agg, float eps, float* sim, int ld_sim,
-                       float* lse, float* wstat, float* attn, const int64_t* attn_off, int strip, int pair_only,
-                       int img_offset, float* amean, int op_dtype, void* stream);
+                       const int32_t* pair_tile, int n_pair, const uint32_t* tile_rowflags, int n_tiles, int n_sent,
+                       int B_img, int D, int S_eff, float temp1, float temp2, float temp3, int agg, float eps,
+                       float* sim, int ld_sim, float* lse, float* wstat, float* attn, const int64_t* attn_off,
+                       int strip, int pair_only, int img_offset, float* amean, int op_dtype, void* stream);
 
 int glr_local_attn_bwd(const void* vt, const void* gram, const void* tp, const float* tnorm,
                        const int32_t* sent_slot0, const int32_t* cap_lens, const int32_t* tile_first,
@@ -185,11 +199,7 @@ int glr_local_attn_bwd(const void* vt, const void* gram, const void* tp, const f
  *   src   row-major [n_blocks * rows][row_bytes]     dst  same size, tiled     row_bytes % 64 == 0
  */
 int glr_tile_k(const void* src, void* dst, int rows, long long n_blocks, int row_bytes, void* stream);
-/* Fragment-major packing for the experimental forward kernel (GLR_K1_T4=1): every 32-row x 32-byte MFMA operand
- * fragment 1 KiB contiguous in lane order; rows % 32 == 0.  glr_set_t4_operands hands the three packed operands
- * (vt, gram, tp; NULL to clear) to the next glr_local_attn_fwd calls of this process. */
-int glr_tile_frag(const void* src, void* dst, int rows, long long n_blocks, int row_bytes, void* stream);
-int glr_set_t4_operands(const void* vt_f, const void* gram_f, const void* tp_f);
+
 
 /* ------------------------------------------------------------------------------------------
  * K2  dual cross-entropy on a square similarity matrix (labels = arange).
@@ -208,16 +218,18 @@ int glr_dual_ce_bwd(const float* sim, int B, const float* lse_row, const float* 
 
 /* ------------------------------------------------------------------------------------------
  * K3  global similarity matrix  sim[b,i] = temp3 * <I_b,T_i> / max(|I_b|*|T_i|, eps).
- * Replaces the norm / bmm / clamp / scale of global_loss (gloria_loss.py:75-80).
+ * Replaces the norm / bmm / clamp / scale of global_loss (gloria_loss.py:75-80): ONE launch per direction on the
+ * matrix cores (exact-fp32 MFMA), row norms fused into the contraction loop, clamp / scale in the epilogue.
  *   img [B_img, D], txt [B_txt, D] fp32;  sim [B_img, ld_sim] fp32; ni[B_img], nt[B_txt] norms (out).
- * bwd: given dsim [B_img, ld_sim] -> dimg [B_img, D] and dtxt [B_txt, D] (dtxt holds only the
- *      contribution of these B_img images: sum across ranks in the data-parallel case).
+ * bwd: given the forward's sim and norms and dsim [B_img, ld_sim] -> dimg [B_img, D] and dtxt [B_txt, D], both
+ *      as MFMA GEMMs whose coefficient operand is formed in registers, incl. torch's sub-gradient of the clamp
+ *      (dtxt holds only the contribution of these B_img images: sum across ranks in the data-parallel case).
  */
 int glr_global_sim_fwd(const float* img, const float* txt, int B_img, int B_txt, int D, float temp3,
                        float eps, float* sim, int ld_sim, float* ni, float* nt, void* stream);
-int glr_global_sim_bwd(const float* img, const float* txt, const float* ni, const float* nt,
-                       const float* dsim, int ld_sim, int B_img, int B_txt, int D, float temp3, float eps,
-                       float* dimg, float* dtxt, void* stream);
+int glr_global_sim_bwd(const float* img, const float* txt, const float* ni, const float* nt, const float* sim,
+                       const float* dsim, int ld_sim, int B_img, int B_txt, int D, float temp3, float eps, float* dimg,
+                       float* dtxt, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * K5  word-piece -> word aggregation (segment sum) fused with the reduction over the last BERT layers

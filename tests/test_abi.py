@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(handle, n), f"{n} declared in include/glr.h but not exported"
     assert sorted(N.SYMBOLS) == names, "ctypes table and header disagree"
-    assert N.lib().glr_version() == 1
+    assert N.lib().glr_version() == 2
 
 
 def test_region_pad():

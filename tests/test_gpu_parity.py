@@ -178,6 +178,29 @@ def test_global_loss_golden(golden, name):
     check(gd, f"global/{name}/grad_txt", tt.grad, rtol=1e-3, atol=1e-6)
 
 
+@pytest.mark.parametrize("shape", [(32, 256, 768), (5, 13, 70), (33, 31, 100), (256, 64, 768)])
+def test_global_similarity_rectangular_vs_oracle(shape):
+    """K3 (fp32 MFMA) on block-row shapes of the data-parallel layout and on sizes that are no multiple of the
+    32-wide tiles / 8-wide k groups, forward and both gradients, incl. an eps-clamped zero row"""
+    Bi, Bt, D = shape
+    img, txt = gi.normal(901 + Bi, Bi, D), gi.normal(902 + Bt, Bt, D)
+    img[Bi // 2] = 0.0
+    a, t = g(img, True), g(txt, True)
+    sim = gl().global_similarity(a, t)
+    ra, rt = torch.from_numpy(img).requires_grad_(True), torch.from_numpy(txt).requires_grad_(True)
+    want = orc().global_similarity_matrix(ra, rt)
+    np.testing.assert_allclose(sim.detach().cpu().numpy(), want.detach().numpy(), rtol=1e-5, atol=1e-5)
+    w = torch.from_numpy(gi.normal(903, Bi, Bt))
+    (sim * w.to(DEV)).sum().backward()
+    (want * w).sum().backward()
+    keep = np.arange(Bi) != Bi // 2
+    np.testing.assert_allclose(a.grad.cpu().numpy()[keep], ra.grad.numpy()[keep], rtol=1e-4, atol=1e-6)
+    zr, zw = a.grad.cpu().numpy()[Bi // 2], ra.grad.numpy()[Bi // 2]          # (temp3 / eps)-scaled row
+    np.testing.assert_allclose(zr / np.abs(zw).max(), zw / np.abs(zw).max(), atol=1e-4)
+    np.testing.assert_allclose(t.grad.cpu().numpy() / np.abs(rt.grad.numpy()).max(),
+                               rt.grad.numpy() / np.abs(rt.grad.numpy()).max(), atol=1e-5)
+
+
 # ------------------------------------------------------------------ (2) oracle on seeded inputs, edge cases
 
 EDGE = {
@@ -250,9 +273,9 @@ BF16_CASES = {
 # the bound is 2^-9 = 2e-3); cos inherits that, sim = temp3 log sum_w exp(temp2 cos_w) amplifies it by at most
 # temp3 temp2 = 50: |d sim| <~ 50 * 2e-3 = 0.1 worst case, ~0.01 typical.  Gradients carry the same relative error
 # plus the bf16 rounding of the backward's X / a2 GEMM operands (2^-9 each): ~1 % relative Frobenius worst case.
-BF16_SIM_ATOL = 0.06
+BF16_SIM_ATOL = 0.02          # observed on MI355X (round 2): 0.002 .. 0.006 over the four bf16 cases
 BF16_MAP_RTOL = 2e-2          # attention maps: a2 = e2 / Z with the bf16 image of e2 (2^-8 relative) over the fp32 Z
-BF16_GRAD_REL = 0.02
+BF16_GRAD_REL = 0.02          # observed: 0.004 .. 0.007 relative Frobenius error
 
 
 @pytest.mark.parametrize("name", list(BF16_CASES))

@@ -163,3 +163,40 @@ def test_unloadable_hyper_parameters_are_reported(tmp_path):
     torch.save({"state_dict": {}, "hyper_parameters": fractions.Fraction(1, 3)}, path)   # any non-allow-listed class
     with pytest.raises(RuntimeError, match="weights-only loader refused"):
         builder.build_gloria_from_ckpt(str(path))
+
+
+def test_plan_rowflags_match_python_restatement():
+    """glr_plan_rowflags: run starts / ends / owners per tile and lane half against a direct Python walk of the
+    slots (row k of half h = slots with ((w >> 2) & 1) == h in word order)"""
+    from gloria import _native as N
+    rng = np.random.default_rng(5)
+    checked = 0
+    for trial in range(20):
+        n = int(rng.integers(1, 40))
+        lens = [int(x) for x in rng.integers(1, 129 if trial % 3 == 0 else 41, size=n)]
+        plan = N.TilePlan(lens, "cpu")
+        if not plan.n_pair:
+            continue
+        flags = plan.rowflags_host
+        slot0 = plan.sent_slot0_host
+        want = np.zeros_like(flags)
+        row_of = lambda w: 16 * (w >> 5) + 4 * ((w & 31) >> 3) + (w & 3)   # noqa: E731
+        for i, ln in enumerate(lens):
+            k = (ln + 63) // 64
+            for sub in range(k):
+                t = slot0[i] // 64 + sub
+                a = slot0[i] % 64 if k == 1 else 0
+                e = a + ln if k == 1 else min(64, ln - sub * 64)
+                for hh in range(2):
+                    ws = [w for w in range(a, e) if ((w >> 2) & 1) == hh]
+                    if not ws:
+                        continue
+                    want[t, hh] |= 1 << row_of(ws[0])
+                    want[t, 2 + hh] |= 1 << row_of(ws[-1])
+                    if sub == 0 and ws[0] == a:
+                        want[t, 4 + hh] |= 1 << row_of(ws[0])
+        assert np.array_equal(flags, want), (lens, flags, want)
+        owners = sum(bin(int(x)).count("1") for x in flags[:, 4:6].reshape(-1))
+        assert owners == n                      # exactly one owner run per sentence
+        checked += 1
+    assert checked >= 5

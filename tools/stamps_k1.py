@@ -51,8 +51,8 @@ if not bwd:
     s2 = buf2.cpu().numpy().reshape(grid, 12)
     s2 = s2[s2[:, 0] > 0]
     if len(s2):
-        n2 = ["setup (plan loads, tables)", "P1 gemm (128 words)", "table init + run max", "run sum + lse", "P2 A+B",
-              "P3 gemm (128 words)", "P4 region sums", "P4 cosine/aggregate/maps"]
+        n2 = ["setup (plan loads, tables)", "P1 gemm (128 words)", "table init + pass 1 (run max)", "pass 2 (run sum)",
+              "P2 (lse, a1, e2, image, dot)", "P3 gemm (128 words)", "P4 Z + region sums", "P4 cosine/aggregate/maps"]
         d2 = np.diff(s2[:, :9].astype(np.float64), axis=1)
         t2 = (s2[:, 8] - s2[:, 0]).astype(np.float64)
         print(f"fwd PAIR kernel: workgroups {len(s2)}, median cycles per pair {np.median(t2):.0f}")
