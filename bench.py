@@ -63,17 +63,39 @@ def _median(xs):
     return xs[len(xs) // 2]
 
 
-def cpu_baseline(sample_batch=16, steps=3):
+def _say(msg):
+    print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
+
+def cpu_baseline(sample_batch=16, full=False):
     """Reference-structured CPU path: the oracle's per-sentence loss loop + the same torch encoders
-    on the host cores.  Bounded sample: `steps` full training steps at B = 16 after one warm-up (median), and the
-    loss alone on synthetic embeddings: forward + backward at B = 16 / 64 (median of 5 / 3), forward at B = 256."""
+    on the host cores (torch's default thread count = the cores available to the process).  A BOUNDED sample (every leg stops adding repetitions once its
+    time budget is spent; medians): full training steps at B = 16 (the metric's unit -> `value`), and the loss alone
+    on synthetic embeddings: forward + backward at B = 16 and B = 64; with --cpu-full also the loss forward at the
+    bench size B = 256 (minutes of CPU time: not part of the default run)."""
     from gloria import builder
     from gloria.config import pretrain_config
     from gloria.datasets.synthetic import make_batch
     from oracle import gloria_oracle as orc
     import numpy as np
-    cores = os.cpu_count() or torch.get_num_threads()
-    torch.set_num_threads(cores)
+    # torch's own default = the cores this process may use (OpenMP honours the affinity mask / cgroup share of the
+    # box; forcing os.cpu_count() over-subscribes a shared host); GLR_CPU_THREADS overrides
+    if os.environ.get("GLR_CPU_THREADS"):
+        torch.set_num_threads(int(os.environ["GLR_CPU_THREADS"]))
+    cores = torch.get_num_threads()
+
+    def sample(fn, max_reps, budget_s, warm=0):
+        ts = []
+        for i in range(warm + max_reps):
+            t0 = time.perf_counter()
+            fn()
+            dt = time.perf_counter() - t0
+            if i >= warm:
+                ts.append(dt)
+            if i >= warm and sum(ts) > budget_s:
+                break
+        return _median(ts), len(ts)
+
     cfg = pretrain_config("imagenome", batch_size=sample_batch)
     torch.manual_seed(1234)
     model = builder.build_gloria_model(cfg)
@@ -81,29 +103,28 @@ def cpu_baseline(sample_batch=16, steps=3):
     params = [p for p in model.parameters() if p.requires_grad]
     opt = torch.optim.Adam(params, lr=5e-5, weight_decay=1e-6, betas=(0.5, 0.999))
     batch = make_batch(sample_batch, seed=1234, lengths="words")
-    times = []
-    for it in range(steps + 1):                  # first iteration = warm-up (allocator, MKL init)
-        t0 = time.perf_counter()
+
+    def step():
         il, ig, tl, tg, sents = model(batch)
         loss, _ = orc.calc_loss(il, ig, tl, tg, sents, temp1=4.0, temp2=5.0, temp3=10.0)
         opt.zero_grad(set_to_none=True)
         loss.backward()
         torch.nn.utils.clip_grad_norm_(params, 0.25)
         opt.step()
-        times.append(time.perf_counter() - t0)
-    step_s = _median(times[1:])
+
+    _say(f"cpu_baseline: full training steps at B={sample_batch} on {cores} threads ...")
+    step_s, n_step = sample(step, 5, 25.0, warm=1)
     del model, opt, params
 
-    def loss_only(B, backward, reps):
+    def loss_fn(B, backward):
         g = torch.Generator().manual_seed(1234 + B)
         img = (torch.randn(B, 768, 19, 19, generator=g) * 0.5).requires_grad_(backward)
         words = (torch.randn(B, 768, 97, generator=g) * 0.5).requires_grad_(backward)
         ig = (torch.randn(B, 768, generator=g) * 0.5).requires_grad_(backward)
         tg = (torch.randn(B, 768, generator=g) * 0.5).requires_grad_(backward)
         lens = sorted((int(x) + 1 for x in np.random.default_rng(1234).integers(4, 40, size=B)), reverse=True)
-        ts = []
-        for _ in range(reps):
-            t0 = time.perf_counter()
+
+        def run():
             with torch.set_grad_enabled(backward):
                 l = orc.local_loss(img, words, lens)
                 gl_ = orc.global_loss(ig, tg)
@@ -111,16 +132,18 @@ def cpu_baseline(sample_batch=16, steps=3):
             if backward:
                 tot.backward()
                 img.grad = words.grad = ig.grad = tg.grad = None
-            ts.append(time.perf_counter() - t0)
-        return _median(ts)
+        return run
 
-    loss = {"B16_fwd_bwd_s": loss_only(16, True, 5), "B64_fwd_bwd_s": loss_only(64, True, 3),
-            "B256_fwd_s": loss_only(256, False, 1)}
+    loss = {}
+    for B, bwd, reps, budget in ((16, True, 5, 6.0), (64, True, 5, 12.0)) + (((256, False, 1, 0.0),) if full else ()):
+        _say(f"cpu_baseline: loss {'fwd+bwd' if bwd else 'fwd'} at B={B} ...")
+        t, n = sample(loss_fn(B, bwd), reps, budget)
+        loss[f"B{B}_{'fwd_bwd' if bwd else 'fwd'}_s"] = t
+        loss[f"B{B}_reps"] = n
     return {"value": sample_batch / step_s, "unit": "pairs/s", "cores": cores, "kind": "port",
-            "sample": f"median of {steps} full training steps (ResNet-50 + BERT-base fwd/bwd + reference-structured "
+            "sample": f"median of {n_step} full training step(s) (ResNet-50 + BERT-base fwd/bwd + reference-structured "
                       f"per-sentence local/global loss loop + clip + Adam) at B={sample_batch}, fp32, torch CPU ops, "
-                      f"after 1 warm-up step; loss_only = the loss loop alone on synthetic embeddings "
-                      f"(median of 5 / 3 / 1 runs)",
+                      f"after 1 warm-up step; loss_only = the loss loop alone on synthetic embeddings (medians)",
             "step_s": step_s, "loss_only": loss}
 
 
@@ -134,6 +157,7 @@ def main():
                     help="words: caption WORD counts ~ U{4..39} (SURVEY.md 8d, the metric's workload); mix: round 1's "
                          "word-PIECE counts ~ U{4..39}; max: every caption at the 97-token limit")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-full", action="store_true", help="cpu_baseline also runs the loss forward at B = 256 (minutes)")
     ap.add_argument("--bert-layers", type=int, default=12)
     ap.add_argument("--global-batch", type=int, default=GLOBAL_BATCH,
                     help="experiments only: the metric is defined at the default 256")
@@ -171,6 +195,7 @@ def main():
             dctx.barrier()
         torch.cuda.synchronize()
 
+    _say(f"model built; {args.warmup} warm-up + {args.steps} timed steps at per-GPU batch {per_rank} ...")
     for _ in range(args.warmup):
         trainer.training_step(model, batch)
     sync()
@@ -248,7 +273,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             # free the GPU-side model first; the CPU leg builds its own copy
-            rec["cpu_baseline"] = cpu_baseline()
+            rec["cpu_baseline"] = cpu_baseline(full=args.cpu_full)
         print(json.dumps(rec), flush=True)
     if dctx:
         dctx.barrier()

@@ -131,7 +131,47 @@ __global__ void __launch_bounds__(256) k_threshold_counts(const float* __restric
   if (threadIdx.x < 4) out[(size_t)blockIdx.x * 4 + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
 
+// Nearest-upsampling footprint counts (the localization metrics WITHOUT the 224 x 224 overlay).
+// nn.Upsample(size=(Hl, Wl)) of an ih x iw map (callbacks.py:319, mode 'nearest') copies cell
+// (min(floor(y ih / Hl), ih - 1), min(floor(x iw / Wl), iw - 1)) - torch's fp32 rule - to pixel (y, x): every
+// pixel statistic of the overlay is a statistic of <= ih * iw cell values weighted by how many pixels (npix) and how
+// many LABEL pixels (cnt) each cell covers.  One workgroup per (image, row band of one cell row): reads its band
+// of the label once (HBM-bound: Hl * Wl bytes per image), integer LDS counters.
+__global__ void __launch_bounds__(256) k_cell_counts(const unsigned char* __restrict__ labels, int Hl, int Wl, int ih,
+                                                     int iw, int* __restrict__ cnt, int* __restrict__ npix) {
+  extern __shared__ int cs[];                     // [iw] label pixels, [iw] pixels
+  const int b = blockIdx.y, ry = blockIdx.x;
+  for (int i = threadIdx.x; i < 2 * iw; i += 256) cs[i] = 0;
+  __syncthreads();
+  const float sy = (float)ih / (float)Hl, sx = (float)iw / (float)Wl;
+  // rows of this band: a superset [y0, y1) from the real-valued bounds, membership decided by the fp32 rule itself
+  const int y0 = max(0, (int)floorf((float)ry / sy) - 2), y1 = min(Hl, (int)ceilf((float)(ry + 1) / sy) + 2);
+  const unsigned char* lab = labels + (size_t)b * Hl * Wl;
+  for (int y = y0; y < y1; ++y) {
+    if (min((int)floorf((float)y * sy), ih - 1) != ry) continue;
+    for (int x = threadIdx.x; x < Wl; x += 256) {
+      const int rx = min((int)floorf((float)x * sx), iw - 1);
+      atomicAdd(&cs[iw + rx], 1);
+      if (lab[(size_t)y * Wl + x]) atomicAdd(&cs[rx], 1);
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < iw; i += 256) {
+    cnt[((size_t)b * ih + ry) * iw + i] = cs[i];
+    npix[((size_t)b * ih + ry) * iw + i] = cs[iw + i];
+  }
+}
+
 }  // namespace
+
+extern "C" int glr_cell_counts(const uint8_t* labels, int B, int Hl, int Wl, int ih, int iw, int32_t* cnt,
+                               int32_t* npix, void* stream) {
+  if (!labels || !cnt || !npix || B <= 0 || Hl <= 0 || Wl <= 0 || ih <= 0 || iw <= 0 || iw > 4096) return GLR_EINVAL;
+  hipLaunchKernelGGL(k_cell_counts, dim3(ih, B), dim3(256), 2 * iw * sizeof(int), (hipStream_t)stream, labels, Hl, Wl,
+                     ih, iw, cnt, npix);
+  GLR_CHECK_LAUNCH();
+  return GLR_OK;
+}
 
 extern "C" int glr_kth_value(const float* x, int rows, long long n, long long k, float* out, void* stream) {
   if (!x || !out || rows <= 0 || n <= 0 || k < 1 || k > n || n >= (1ll << 32)) return GLR_EINVAL;

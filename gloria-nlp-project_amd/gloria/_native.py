@@ -43,6 +43,7 @@ SYMBOLS = {
     "glr_bn_workspace_floats": (c_int, [ctypes.c_longlong, c_int]),
     "glr_bn_act_fwd": (c_int, [c_void_p] * 4 + [ctypes.c_longlong, c_int, c_float, c_float, c_int] + [c_void_p] * 7),
     "glr_bn_act_bwd": (c_int, [c_void_p] * 7 + [ctypes.c_longlong, c_int, c_int, c_int] + [c_void_p] * 7),
+    "glr_cell_counts": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "glr_kth_value": (c_int, [c_void_p, c_int, ctypes.c_longlong, ctypes.c_longlong, c_void_p, c_void_p]),
     "glr_topk_desc": (c_int, [c_void_p, c_int, ctypes.c_longlong, c_int, c_void_p, c_void_p, c_void_p]),
     "glr_threshold_counts": (c_int, [c_void_p, c_void_p, c_void_p, c_int, ctypes.c_longlong, c_void_p, c_void_p]),

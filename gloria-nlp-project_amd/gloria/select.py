@@ -43,3 +43,16 @@ def threshold_counts(pred, target, thr):
     N.check(N.lib().glr_threshold_counts(N.ptr(r), N.ptr(t), N.ptr(th), r.shape[0], r.shape[1], N.ptr(out), N.stream()),
             "glr_threshold_counts")
     return out
+
+
+def cell_counts(labels, ih, iw):
+    """labels [B, Hl, Wl] (bool / uint8) -> (cnt, npix) int64 [B, ih * iw]: label pixels / pixels of the
+    nearest-upsampled Hl x Wl overlay that copy each cell of an ih x iw map (glr_cell_counts)."""
+    N.require_cuda(labels)
+    lab = labels.detach().to(torch.uint8).contiguous()
+    B, Hl, Wl = lab.shape
+    cnt = torch.empty(B, ih * iw, dtype=torch.int32, device=lab.device)
+    npix = torch.empty(B, ih * iw, dtype=torch.int32, device=lab.device)
+    N.check(N.lib().glr_cell_counts(N.ptr(lab), B, Hl, Wl, int(ih), int(iw), N.ptr(cnt), N.ptr(npix), N.stream()),
+            "glr_cell_counts")
+    return cnt.long(), npix.long()

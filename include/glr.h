@@ -295,6 +295,13 @@ int glr_attn_reg_bwd(const float* amean, int B_img, int n_sent, int S_pad, int S
  *                        the counts behind precision / recall / F1 / IoU at a percentile threshold (callbacks.py:57-61)
  */
 int glr_kth_value(const float* x, int rows, long long n, long long k, float* out, void* stream);
+/* Footprint counts of nearest upsampling (gloria/lightning/callbacks.py:319 nn.Upsample(size=image_shape), torch's
+ * fp32 floor(dst * in / out) rule): for every cell of an ih x iw map, npix = pixels of the Hl x Wl overlay that copy
+ * it and cnt = those of them set in labels [B, Hl, Wl] (uint8).  cnt, npix: int32 [B, ih, iw].  With them the
+ * localization metrics (callbacks.py:38-70) are exact statistics of ih * iw weighted cell values: the overlay is
+ * never materialised. */
+int glr_cell_counts(const uint8_t* labels, int B, int Hl, int Wl, int ih, int iw, int32_t* cnt, int32_t* npix,
+                    void* stream);
 int glr_topk_desc(const float* x, int rows, long long n, int k, int64_t* idx, float* val, void* stream);
 int glr_threshold_counts(const float* pred, const uint8_t* target, const float* thr, int rows, long long n,
                          uint64_t* out, void* stream);

@@ -48,29 +48,68 @@ def test_kth_value_matches_torch_topk(n):
 
 
 def test_localization_metrics_match_cpu_restatement():
-    """callbacks.py:52-61 restated with torch CPU ops on the same maps."""
+    """`Metrics` of callbacks.py:26-70 restated on the CPU with the overlay MATERIALISED (nn.Upsample nearest, :319)
+    against the product's cell-based GPU evaluation that never forms it.  Threshold, counts-based metrics: exact;
+    AUROC / AP against scikit-learn on the 50 176 pixels (the definitions torchmetrics ported); entropy against
+    torch.distributions.Categorical exactly as callbacks.py:16-19.  Maps 3 and 4 hold tied cell values."""
+    from sklearn.metrics import average_precision_score, roc_auc_score
+    from torch.distributions.categorical import Categorical
     from gloria.lightning.callbacks import Metrics
     g = torch.Generator().manual_seed(5)
     maps = torch.rand(6, 19, 19, generator=g)
-    overlay = torch.nn.functional.interpolate(maps[:, None], size=(224, 224))[:, 0]      # nearest, as the callback
-    label = torch.zeros(6, 224, 224, dtype=torch.bool)
-    for i in range(5):                                                                   # last label stays empty
+    maps = maps / maps.sum((1, 2), keepdim=True) * torch.tensor([1.0, 0.9, 0.7, 1.0, 0.5, 1.0]).view(6, 1, 1)
+    maps[3] = (maps[3] * 2000).round() / 2000                 # heavy ties between cells
+    maps[4, 5:9] = maps[4, 5, 0]
+    H, W = 224, 224
+    overlay = torch.nn.Upsample(size=(H, W))(maps[:, None])[:, 0]
+    label = torch.zeros(6, H, W, dtype=torch.bool)
+    for i in range(5):                                        # last label stays empty
         label[i, 20 * i:20 * i + 60, 30:30 + 25 * (i + 1)] = True
-    out = Metrics()(overlay.to(DEV), label.to(DEV))
-    total = 224 * 224
-    for p in (.05, .1, .2, .3):
-        for i in range(6):
-            preds, targets = overlay[i].reshape(-1), label[i].reshape(-1)
-            thr = torch.topk(preds, total - int(total * p), largest=False).values.max()
-            assert float(out["threshold_at_%f" % p][i]) == float(thr)
-            if i == 5:
-                assert torch.isnan(out["iou_at_%f" % p][i])
-                continue
-            m = preds > thr
-            tp = (m & targets).sum().item()
-            np.testing.assert_allclose(float(out["precision_at_%f" % p][i]), tp / max(m.sum().item(), 1), rtol=1e-12)
-            np.testing.assert_allclose(float(out["recall_at_%f" % p][i]), tp / targets.sum().item(), rtol=1e-12)
-            np.testing.assert_allclose(float(out["iou_at_%f" % p][i]), tp / (m | targets).sum().item(), rtol=1e-12)
+    out = Metrics()(maps.to(DEV), label.to(DEV), curves=True)
+    total = H * W
+    for i in range(6):
+        preds, tg = overlay[i].reshape(-1), label[i].reshape(-1)
+        flat = maps[i].reshape(-1)
+        ent = Categorical(torch.cat([(1 - flat.sum(-1)).unsqueeze(0), flat], 0)).entropy()
+        np.testing.assert_allclose(float(out["attn_entropy"][i]), float(ent), rtol=1e-6)
+        np.testing.assert_allclose(float(out["no_attn_weight"][i]), float(1 - flat.sum(-1)), atol=1e-6)
+        if tg.sum() == 0:
+            for k, v in out.items():
+                if k.startswith(("precision", "recall", "f1", "iou", "auroc", "avg")):
+                    assert torch.isnan(v[i]), k
+            continue
+        np.testing.assert_allclose(float(out["auroc"][i]), roc_auc_score(tg.numpy(), preds.numpy()), rtol=1e-9)
+        np.testing.assert_allclose(float(out["avg_precision"][i]), average_precision_score(tg.numpy(), preds.numpy()),
+                                   rtol=1e-9)
+        fpr, tpr, _ = out["roc_curve"][i]
+        assert float(fpr[0]) == 0 and float(tpr[0]) == 0 and float(fpr[-1]) == 1 and float(tpr[-1]) == 1
+        for p in (.05, .1, .2, .3):
+            top_k = int(total * p)
+            thr = torch.topk(preds, total - top_k, largest=False).values.max()
+            assert float(out["threshold_at_%f" % p][i]) == float(thr)             # the same float
+            ge, gt = preds >= thr, preds > thr                                     # torchmetrics binarises with >=
+            tp = float((ge & tg).sum())
+            pr, re = tp / float(ge.sum()), tp / float(tg.sum())
+            np.testing.assert_allclose(float(out["precision_at_%f" % p][i]), pr, rtol=1e-12)
+            np.testing.assert_allclose(float(out["recall_at_%f" % p][i]), re, rtol=1e-12)
+            np.testing.assert_allclose(float(out["f1_at_%f" % p][i]), 2 * pr * re / (pr + re), rtol=1e-12)
+            iou = float((gt & tg).sum()) / float((gt | tg).sum())                  # callbacks.py:59-60, strict mask
+            np.testing.assert_allclose(float(out["iou_at_%f" % p][i]), iou, rtol=1e-12)
+
+
+@pytest.mark.parametrize("shape", [(224, 224, 19, 19), (300, 257, 19, 19), (97, 131, 7, 5), (19, 19, 19, 19)])
+def test_cell_counts_match_materialised_upsample(shape):
+    """glr_cell_counts against counting on the explicitly upsampled index map (torch's nearest rule)"""
+    H, W, ih, iw = shape
+    rng = np.random.default_rng(H * 1000 + W)
+    lab = torch.from_numpy(rng.random((3, H, W)) < 0.3)
+    cnt, npix = sel().cell_counts(lab.to(DEV), ih, iw)
+    cell = torch.arange(ih * iw, dtype=torch.float32).view(1, 1, ih, iw)
+    idx = torch.nn.Upsample(size=(H, W))(cell)[0, 0].long().reshape(-1)
+    for b in range(3):
+        want_n = torch.bincount(idx, minlength=ih * iw)
+        want_c = torch.bincount(idx, weights=lab[b].reshape(-1).double(), minlength=ih * iw).long()
+        assert torch.equal(npix[b].cpu(), want_n) and torch.equal(cnt[b].cpu(), want_c)
 
 
 def test_retriever_ranking_matches_reference_structured_cpu():
