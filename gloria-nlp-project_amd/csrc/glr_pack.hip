@@ -7,6 +7,7 @@
 // glr_pack_words   word slices of every sentence, word-major, plus their L2 norms (:14, :122).
 #include <string.h>
 
+#include <algorithm>
 #include <vector>
 
 #include "glr_common.h"
@@ -49,6 +50,31 @@ extern "C" int glr_plan_tiles(const int32_t* cap_lens, int n_sent, int capacity,
     sent_slot0[i] = (int)t * GLR_TILE_WORDS + fill[t];
     fill[t] += n;
     members[t].push_back(i);
+  }
+  // Tile ORDER is free (a tile is just 64 consecutive slots): the forward pairs consecutive ordinary tiles and a
+  // pair may hold at most 8 sentences, while first fit over length-sorted captions leaves the many short
+  // sentences in the last tiles.  Ordinary tiles are therefore re-ordered so that neighbours are balanced:
+  // fewest sentences next to most, second fewest next to second most, ...  (multi-tile sentences keep their runs).
+  {
+    std::vector<size_t> ord_idx;
+    for (size_t t = 0; t < members.size(); ++t) if (nsub[t] == 0) ord_idx.push_back(t);
+    std::vector<size_t> by_cnt(ord_idx);
+    std::stable_sort(by_cnt.begin(), by_cnt.end(), [&](size_t a, size_t b) { return members[a].size() < members[b].size(); });
+    std::vector<size_t> seq;
+    for (size_t lo = 0, hi = by_cnt.size(); lo < hi;) {
+      seq.push_back(by_cnt[lo++]);
+      if (lo < hi) seq.push_back(by_cnt[--hi]);
+    }
+    std::vector<std::vector<int>> m2(members);
+    std::vector<int> f2(fill);
+    for (size_t i = 0; i < ord_idx.size(); ++i) { m2[ord_idx[i]] = members[seq[i]]; f2[ord_idx[i]] = fill[seq[i]]; }
+    members.swap(m2);
+    fill.swap(f2);
+    for (size_t t = 0; t < members.size(); ++t) {
+      if (nsub[t] != 0) continue;
+      int pos = 0;
+      for (int s : members[t]) { sent_slot0[s] = (int)t * GLR_TILE_WORDS + pos; pos += cap_lens[s]; }
+    }
   }
   int k = 0;
   for (size_t t = 0; t < members.size(); ++t) {

@@ -40,9 +40,11 @@ SYMBOLS = {
                                    c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
                                    # sim, dsim, ld, lse, wstat, damean, dattn, attn_off, strip, img_offset,
                                    # xout, aout, gamma, beta, dtype, stream
-    "glr_bn_workspace_floats": (c_int, [ctypes.c_longlong, c_int]),
-    "glr_bn_act_fwd": (c_int, [c_void_p] * 4 + [ctypes.c_longlong, c_int, c_float, c_float, c_int] + [c_void_p] * 7),
-    "glr_bn_act_bwd": (c_int, [c_void_p] * 7 + [ctypes.c_longlong, c_int, c_int, c_int] + [c_void_p] * 7),
+    "glr_sumsq_blocks": (c_int, [ctypes.c_longlong]),
+    "glr_sumsq_partial": (c_int, [c_void_p, c_int, ctypes.c_longlong, c_void_p, c_void_p]),
+    "glr_clip_coef": (c_int, [c_void_p, c_int, c_float, c_void_p, c_void_p]),
+    "glr_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, ctypes.c_longlong, c_float,
+                              c_float, c_float, c_float, c_float, c_int, c_void_p, c_void_p]),
     "glr_cell_counts": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "glr_kth_value": (c_int, [c_void_p, c_int, ctypes.c_longlong, ctypes.c_longlong, c_void_p, c_void_p]),
     "glr_topk_desc": (c_int, [c_void_p, c_int, ctypes.c_longlong, c_int, c_void_p, c_void_p, c_void_p]),

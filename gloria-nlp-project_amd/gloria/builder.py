@@ -80,6 +80,19 @@ def build_optimizer(cfg, lr, model):
             p.requires_grad = True
     params = [p for p in model.parameters() if p.requires_grad]
 
+    if cfg.train.optimizer.name == "Adam" and cfg.train.optimizer.flat_bf16 and params and all(p.is_cuda for p in params):
+        # MI355X training path (set by gloria.trainer.Trainer for bf16 runs): the same Adam on flat fp32 masters with
+        # bf16 shadow weights, gradient clipping folded in (gloria/optim.py).  Parameters the graph never reaches get
+        # no gradient and are skipped by torch.optim.Adam; the flat optimizer leaves them out altogether: the BERT
+        # pooler when last_n_layers > 1 (BertEncoder.forward then ignores outputs[1], text_model.py:96-114).
+        from .optim import ShadowAdam, shadow_parameter_ids
+        skip = set()
+        if (cfg.model.text.last_n_layers or 1) > 1 and hasattr(model, "text_encoder"):
+            skip = {id(p) for p in model.text_encoder.model.pooler.parameters()}
+        params = [p for p in params if id(p) not in skip]
+        return ShadowAdam(params, lr=lr, betas=(0.5, 0.999), weight_decay=float(cfg.train.optimizer.weight_decay),
+                          max_grad_norm=cfg.train.optimizer.flat_clip, shadow_ids=shadow_parameter_ids(model))
+
     if cfg.train.optimizer.name == "SGD":
         return torch.optim.SGD(params, lr=lr, momentum=cfg.momentum, weight_decay=cfg.weight_decay)
     elif cfg.train.optimizer.name == "Adam":

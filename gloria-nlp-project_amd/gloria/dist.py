@@ -122,8 +122,34 @@ class GradReducer:
     launched asynchronously on the collective stream while backward keeps running.  `finish()` waits for
     all buckets.  xGMI is point-to-point: few large buckets (64 MiB) keep RCCL on all links."""
 
+    @classmethod
+    def from_flat(cls, groups, ctx, bucket_bytes=64 << 20):
+        """groups: [(flat gradient buffer, [params in buffer order], [element offsets])] of a flat optimizer
+        (gloria.optim.ShadowAdam) whose `.grad`s already are views of those buffers.  Buckets are consecutive
+        parameter ranges of a buffer (>= bucket_bytes each), all-reduced as slices: nothing is copied or re-laid."""
+        self = cls.__new__(cls)
+        self.ctx, self.buckets, self._views, self._fired = ctx, [], {}, set()
+        self._hide_unused = False         # every parameter of a flat optimizer is stepped: its zero gradient is real
+        for flat, plist, offs in groups:
+            start, cur = 0, []
+            for i, p in enumerate(plist):
+                cur.append(p)
+                end = offs[i + 1] if i + 1 < len(plist) else flat.numel()
+                if (end - offs[start]) * flat.element_size() >= bucket_bytes or i + 1 == len(plist):
+                    idx = len(self.buckets)
+                    self.buckets.append((flat[offs[start]:end], cur))
+                    for q in cur:
+                        self._views[q] = q.grad
+                        q.register_post_accumulate_grad_hook(lambda _p, k=idx: self._on_ready(k, _p))
+                    start, cur = i + 1, []
+        self._pending = []
+        self._ready = [0] * len(self.buckets)
+        self._open = False
+        return self
+
     def __init__(self, params, ctx, bucket_bytes=64 << 20):
         self.ctx = ctx
+        self._hide_unused = True
         self.buckets = []                 # (flat tensor, [params])
         self._views = {}                  # param -> its gradient view into the bucket
         self._fired = set()               # params whose gradient arrived in the current backward
@@ -187,6 +213,8 @@ class GradReducer:
         self._open = False
         # a parameter no rank used (e.g. the BERT pooler with last_n_layers > 1) must look to the optimizer as it
         # does in the single-process run - grad None, skipped - not as a zero gradient that weight decay acts on
+        if not self._hide_unused:
+            return
         for _, plist in self.buckets:
             for p in plist:
                 if p not in self._fired:

@@ -1,0 +1,162 @@
+"""Flat-buffer Adam with bf16 shadow weights: the parameter-sized work of one optimisation step in a handful of
+launches (include/glr.h: glr_sumsq_partial / glr_clip_coef / glr_adam_step).
+
+The reference trains under Lightning's native AMP with `torch.optim.Adam(betas=(0.5, 0.999))` and
+`gradient_clip_val 0.25` (/root/reference/gloria/builder.py:84-87, run.py:172-207).  Done with stock torch pieces that
+is, per step and independent of the batch size: one fp32->bf16 cast per weight (autocast), one bf16->fp32 cast per
+gradient, ~130 fills, a 70-launch gradient-norm reduction, the clip multiply and the optimizer - about 600 launches
+and 7 ms on one MI355X, which is what bounds a data-parallel rank at 32 pairs per GPU.  Here:
+
+  * every trainable parameter lives in ONE flat fp32 master buffer (plus flat exp_avg / exp_avg_sq);
+  * parameters of Linear / Conv modules are bf16 VIEWS of a flat shadow buffer that the Adam kernel
+    rewrites from the masters - the forward needs no weight cast; their gradients arrive as bf16 views of a flat
+    gradient buffer (what autocast's backward produces before its cast) - no gradient cast;
+  * normalisation parameters, embeddings and everything else stay fp32 (views of the master buffer itself);
+  * the gradient norm of clip_grad_norm_ is two launches over the flat gradient buffers, its coefficient never
+    leaves the device and is applied inside the Adam kernel;
+  * zero_grad is one memset per flat buffer; the flat gradient buffers are the all-reduce buckets of the
+    data-parallel reducer (gloria.dist.GradReducer.from_flat).
+
+Numerics are those of the AMP recipe: bf16(master) is exactly what autocast's cast hands the forward, and the fp32
+Adam update runs on the masters.
+"""
+
+import torch
+
+from . import _native as N
+
+
+def _storage_flat(t):
+    """1-D view of a dense tensor's elements in MEMORY order (channels-last conv weights stay as they lie)."""
+    return torch.as_strided(t, (t.numel(),), (1,), t.storage_offset())
+
+
+class _Group:
+    def __init__(self, params, shadow, device):
+        self.params, self.shadow = params, shadow
+        self.offsets, off = [], 0
+        for p in params:
+            self.offsets.append(off)
+            off += (p.numel() + 7) // 8 * 8
+        self.n = off
+        f32 = dict(dtype=torch.float32, device=device)
+        self.master = torch.zeros(self.n, **f32)
+        self.exp_avg = torch.zeros(self.n, **f32)
+        self.exp_avg_sq = torch.zeros(self.n, **f32)
+        gdt = torch.bfloat16 if shadow else torch.float32
+        self.grad = torch.zeros(self.n, dtype=gdt, device=device)
+        self.shadow_buf = torch.zeros(self.n, dtype=torch.bfloat16, device=device) if shadow else None
+        for p, o in zip(params, self.offsets):
+            k = p.numel()
+            with torch.no_grad():
+                self.master[o:o + k].copy_(_storage_flat(p.data).float())
+                src = self.shadow_buf if shadow else self.master
+                if shadow:
+                    src[o:o + k].copy_(self.master[o:o + k])
+                p.data = src.as_strided(p.shape, p.stride(), storage_offset=o)
+                p.grad = self.grad.as_strided(p.shape, p.stride(), storage_offset=o)
+
+    def view(self, buf, i):
+        p, o = self.params[i], self.offsets[i]
+        return buf.as_strided(p.shape, p.stride(), storage_offset=o)
+
+
+class ShadowAdam(torch.optim.Optimizer):
+    """Adam (torch semantics) over flat buffers.  `shadow_ids`: ids of the parameters that become bf16 shadows."""
+
+    def __init__(self, params, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_grad_norm=None, shadow_ids=()):
+        params = [p for p in params if p.requires_grad]
+        if not params or not all(p.is_cuda for p in params):
+            raise RuntimeError("ShadowAdam runs on GPU parameters (the flat kernels are HIP)")
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        dev = params[0].device
+        shadow_ids = set(shadow_ids)
+        # reverse registration order: backward produces gradients roughly back to front, so consecutive ranges of a
+        # flat buffer complete together (the reducer's buckets)
+        rev = list(reversed(params))
+        self.groups = [g for g in (_Group([p for p in rev if id(p) in shadow_ids], True, dev),
+                                   _Group([p for p in rev if id(p) not in shadow_ids], False, dev)) if g.params]
+        self.max_grad_norm = float(max_grad_norm) if max_grad_norm else 0.0
+        self.t = 0
+        L = N.lib()
+        self._nblocks = [L.glr_sumsq_blocks(g.n) for g in self.groups]
+        self._partial = torch.zeros(sum(self._nblocks), dtype=torch.float32, device=dev)
+        self.clip_state = torch.zeros(2, dtype=torch.float32, device=dev)          # [norm, coefficient] of the last step
+        for g in self.groups:                     # per-parameter views of the moments: the stock state_dict layout
+            for i, p in enumerate(g.params):
+                self.state[p] = {"step": torch.zeros((), dtype=torch.float32), "exp_avg": g.view(g.exp_avg, i),
+                                 "exp_avg_sq": g.view(g.exp_avg_sq, i)}
+
+    # ---------------------------------------------------------------- one step
+    def zero_grad(self, set_to_none=False):
+        for g in self.groups:
+            g.grad.zero_()
+            for i, p in enumerate(g.params):
+                if p.grad is None or p.grad.data_ptr() != g.grad.data_ptr() + g.offsets[i] * g.grad.element_size():
+                    p.grad = g.view(g.grad, i)
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        L, st = N.lib(), N.stream()
+        o = 0
+        for g, nb in zip(self.groups, self._nblocks):
+            N.check(L.glr_sumsq_partial(N.ptr(g.grad), N.dtype_code(g.grad.dtype), g.n, N.ptr(self._partial[o:]), st),
+                    "glr_sumsq_partial")
+            o += nb
+        N.check(L.glr_clip_coef(N.ptr(self._partial), o, self.max_grad_norm, N.ptr(self.clip_state), st), "glr_clip_coef")
+        self.t += 1
+        pg = self.param_groups[0]
+        for g in self.groups:
+            N.check(L.glr_adam_step(N.ptr(g.master), N.ptr(g.exp_avg), N.ptr(g.exp_avg_sq), N.ptr(g.grad),
+                                    N.dtype_code(g.grad.dtype), N.ptr(g.shadow_buf), g.n, float(pg["lr"]),
+                                    float(pg["betas"][0]), float(pg["betas"][1]), float(pg["eps"]),
+                                    float(pg["weight_decay"]), self.t, N.ptr(self.clip_state), st), "glr_adam_step")
+        for s in self.state.values():
+            s["step"] = torch.tensor(float(self.t))
+
+    # ---------------------------------------------------------------- checkpoints: fp32 masters, stock layout
+    def master_of(self, p):
+        for g in self.groups:
+            for i, q in enumerate(g.params):
+                if q is p:
+                    return g.view(g.master, i)
+        return None
+
+    def load_masters(self, named_fp32):
+        """named_fp32: iterable of (parameter, fp32 tensor): masters (and shadows) are rewritten from it."""
+        with torch.no_grad():
+            for p, t in named_fp32:
+                m = self.master_of(p)
+                if m is not None:
+                    m.copy_(t.to(m.device, torch.float32))
+                    if p.dtype != torch.float32:
+                        p.data.copy_(m)
+
+    def load_state_dict(self, state_dict):
+        """stock layout in, flat buffers out: the moments are copied INTO the flat views"""
+        sd = state_dict["state"]
+        ids = [i for grp in state_dict["param_groups"] for i in grp["params"]]
+        plist = [p for grp in self.param_groups for p in grp["params"]]
+        with torch.no_grad():
+            for i, p in zip(ids, plist):
+                if i in sd:
+                    self.state[p]["exp_avg"].copy_(sd[i]["exp_avg"])
+                    self.state[p]["exp_avg_sq"].copy_(sd[i]["exp_avg_sq"])
+                    self.t = max(self.t, int(float(sd[i]["step"])))
+        for grp, src in zip(self.param_groups, state_dict["param_groups"]):
+            for k in ("lr", "betas", "eps", "weight_decay"):
+                grp[k] = src[k]
+        for s in self.state.values():
+            s["step"] = torch.tensor(float(self.t))
+
+
+def shadow_parameter_ids(model):
+    """parameters autocast would cast to bf16 on every use: those of Linear / Conv modules (weights and biases).
+    Normalisation layers, free-standing parameters and EMBEDDINGS stay fp32: autocast leaves F.embedding alone, and
+    the position / token-type rows collect hundreds of gradient contributions per step, which a bf16 gradient buffer
+    would sum at 8 bits."""
+    ids = set()
+    for m in model.modules():
+        if isinstance(m, (torch.nn.Linear, torch.nn.Conv2d)):
+            ids.update(id(p) for p in m.parameters(recurse=False))
+    return ids

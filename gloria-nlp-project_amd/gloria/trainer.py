@@ -13,7 +13,7 @@ import torch
 
 class Trainer:
     def __init__(self, cfg, device="cuda", precision=None, dist_ctx=None, log_path=None, miopen_benchmark=False,
-                 sync_bn=False):
+                 sync_bn=False, flat_optimizer=None):
         self.cfg = cfg
         self.device = torch.device(device)
         prec = precision if precision is not None else cfg.lightning.trainer.precision
@@ -32,6 +32,12 @@ class Trainer:
         # per-channel all-reduce per layer) - the reference oracle is single-device full-batch BN (SURVEY.md
         # section 7); the default keeps per-rank statistics (speed mode)
         self.sync_bn = bool(sync_bn)
+        # bf16 runs on the GPU keep fp32 master weights + bf16 shadows in flat buffers and do clip + Adam in three
+        # launches (gloria/optim.py); GLR_FLAT_OPTIMIZER=0 or flat_optimizer=False keeps torch's fused Adam + autocast casts
+        if flat_optimizer is None:
+            flat_optimizer = os.environ.get("GLR_FLAT_OPTIMIZER", "1") != "0"
+        self.flat_optimizer = bool(flat_optimizer) and self.device.type == "cuda" and self.autocast_dtype is not None \
+            and cfg.train.optimizer.name == "Adam"
 
     # ------------------------------------------------------------------ setup
     def setup(self, model):
@@ -43,13 +49,21 @@ class Trainer:
         if self.sync_bn and self.dist is not None and self.dist.world_size > 1:
             model.gloria.img_encoder = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model.gloria.img_encoder,
                                                                                       self.dist.group)
+        if self.flat_optimizer:
+            self.cfg.set_path("train.optimizer.flat_bf16", True)
+            self.cfg.set_path("train.optimizer.flat_clip", self.clip)
         opt = model.configure_optimizers()
         self.optimizer, self.scheduler = opt["optimizer"], opt["lr_scheduler"]
         self.params = [p for g in self.optimizer.param_groups for p in g["params"]]
+        from .optim import ShadowAdam
+        self.flat = isinstance(self.optimizer, ShadowAdam)
         self.reducer = None
         if self.dist is not None and self.dist.active:
             from .dist import GradReducer
-            self.reducer = GradReducer(self.params, self.dist)      # grads become views of flat buckets
+            if self.flat:       # the optimizer's flat gradient buffers are the all-reduce buckets
+                self.reducer = GradReducer.from_flat([(g.grad, g.params, g.offsets) for g in self.optimizer.groups], self.dist)
+            else:
+                self.reducer = GradReducer(self.params, self.dist)      # grads become views of flat buckets
         return model
 
     def to_device(self, batch):
@@ -77,9 +91,9 @@ class Trainer:
             loss.backward()                   # bucket all-reduces start as soon as a bucket is complete
             self.reducer.finish()
         else:
-            self.optimizer.zero_grad(set_to_none=True)
+            self.optimizer.zero_grad(set_to_none=not self.flat)
             loss.backward()
-        if self.clip:
+        if self.clip and not self.flat:       # the flat optimizer clips inside its step (post-reduce global norm)
             torch.nn.utils.clip_grad_norm_(self.params, self.clip)
         self.optimizer.step()
         self.global_step += 1
@@ -140,6 +154,11 @@ class Trainer:
     def save_checkpoint(self, model, path):
         os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
         ckpt = model.checkpoint()
+        if self.flat:        # the reference layout holds fp32 weights: write the masters, not the bf16 shadows
+            for name, p in model.named_parameters():
+                m = self.optimizer.master_of(p)
+                if m is not None:
+                    ckpt["state_dict"][name] = m.detach().clone()
         ckpt["optimizer_states"] = [self.optimizer.state_dict()]
         ckpt["global_step"] = self.global_step
         ckpt["epoch"] = model.current_epoch
@@ -148,7 +167,10 @@ class Trainer:
     def resume(self, model, path):
         from .builder import clean_state_dict
         ckpt = torch.load(path, map_location="cpu", weights_only=True)
-        model.load_state_dict(clean_state_dict(ckpt["state_dict"]))
+        sd = clean_state_dict(ckpt["state_dict"])
+        model.load_state_dict(sd)
+        if getattr(self, "flat", False):
+            self.optimizer.load_masters((p, sd[name]) for name, p in model.named_parameters() if name in sd)
         if self.optimizer is not None and "optimizer_states" in ckpt:
             self.optimizer.load_state_dict(ckpt["optimizer_states"][0])
         self.global_step = ckpt.get("global_step", 0)

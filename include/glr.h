@@ -307,25 +307,6 @@ int glr_threshold_counts(const float* pred, const uint8_t* target, const float* 
                          uint64_t* out, void* stream);
 
 /* ------------------------------------------------------------------------------------------
- * Fused training-mode BatchNorm2d (+ residual add) (+ ReLU) on channels-last bf16 activations: the bottleneck
- * epilogues of the ResNet-50 image encoder (reference: torchvision resnet50 through gloria/models/cnn_backbones.py:31-35,
- * vision_model.py:67-86).  x / y / dy / dx / residual: bf16 [R = N*H*W, C] (NHWC memory), C % 8 == 0.
- *   fwd   mean, invstd [C] out (batch statistics, biased variance + eps); run_mean / run_var updated with
- *         `momentum` and the unbiased variance like nn.BatchNorm2d (NULL = no running statistics);
- *         y = relu?( (x - mean) invstd gamma + beta (+ residual) )
- *   bwd   dx, dgamma, dbeta; with a residual also dres = dy * [y > 0] (gradient of the skip branch)
- *   workspace: glr_bn_workspace_floats(R, C) floats; tmp2c: 2 * C floats.
- * HBM-bound; fixed-order two-level reductions (bitwise reproducible).
- */
-int glr_bn_workspace_floats(long long R, int C);
-int glr_bn_act_fwd(const void* x, const void* residual, const float* gamma, const float* beta, long long R, int C,
-                   float eps, float momentum, int relu, float* run_mean, float* run_var, float* mean, float* invstd,
-                   float* workspace, void* y, void* stream);
-int glr_bn_act_bwd(const void* x, const void* dy, const void* y, const float* gamma, const float* beta, const float* mean,
-                   const float* invstd, long long R, int C, int relu, int has_residual, float* workspace, float* dgamma,
-                   float* dbeta, float* tmp2c, void* dx, void* dres, void* stream);
-
-/* ------------------------------------------------------------------------------------------
  * Image half of the collate function: replaces, for a ragged batch of single-channel images,
  *   original_tensor_to_numpy_image   gloria/datasets/mimic_for_gloria.py:36-42  (min-max -> uint8, truncating)
  *   GloriaCollateFn._resize_img      mimic_for_gloria.py:136-181   (cv2.INTER_AREA long side -> scale, zero pad)
@@ -348,6 +329,25 @@ int glr_image_minmax(const void* src, const int64_t* offset, const int32_t* desc
                      uint32_t* state, void* stream);
 int glr_collate_images(const void* src, const int64_t* offset, const int32_t* desc, const uint32_t* state, int B,
                        int src_dtype, int crop, float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Optimisation step over FLAT parameter buffers (the reference delegates it to Lightning: Adam(betas=(0.5, 0.999)),
+ * gradient_clip_val 0.25, native AMP - gloria/builder.py:84-87, run.py:172-207).  n % 8 == 0 (pad the buffers).
+ *   glr_sumsq_blocks    number of partial sums glr_sumsq_partial writes for n elements
+ *   glr_sumsq_partial   partial[blocks] = fixed-order partial sums of squares of x (GLR_F32 / GLR_BF16)
+ *   glr_clip_coef       out[0] = sqrt(sum of all partials) (the global gradient norm), out[1] = the coefficient of
+ *                       torch.nn.utils.clip_grad_norm_: min(1, max_norm / (norm + 1e-6)); stays on the device
+ *   glr_adam_step       torch.optim.Adam on fp32 master weights: g = clip[1] * grad + weight_decay * p,
+ *                       m = b1 m + (1 - b1) g, v = b2 v + (1 - b2) g^2, p -= lr / (1 - b1^step) * m /
+ *                       (sqrt(v) / sqrt(1 - b2^step) + eps); writes the bf16 shadow of p when shadow_bf16 != NULL.
+ *                       clip may be NULL (no clipping).
+ */
+int glr_sumsq_blocks(long long n);
+int glr_sumsq_partial(const void* x, int dtype, long long n, float* partial, void* stream);
+int glr_clip_coef(const float* partial, int n_partial, float max_norm, float* out, void* stream);
+int glr_adam_step(float* master, float* exp_avg, float* exp_avg_sq, const void* grad, int grad_dtype, void* shadow_bf16,
+                  long long n, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                  const float* clip, void* stream);
 
 #ifdef __cplusplus
 }
