@@ -104,7 +104,110 @@ __global__ void __launch_bounds__(OPT_NT) k_adam(float* __restrict__ master, flo
   }
 }
 
+// ---- pointer-table forms: gradients stay where autograd left them (one tensor per parameter, no accumulation
+// into a flat buffer: that costs an add launch per parameter).  One workgroup per chunk of <= OPT_CHUNK elements.
+//   chunk[c] = { parameter index, element offset inside the parameter, element offset in the flat buffers, count }
+//   gptr[param] = device address of the parameter's gradient this step (0: no gradient -> the parameter is skipped,
+//   like torch.optim.Adam skips a None gradient)
+struct ChunkEnt { int param; int count; long long poff; long long foff; };
+
+__device__ __forceinline__ float ld1(const void* p, int dtype, size_t i) {
+  return dtype == GLR_BF16 ? bf2f(reinterpret_cast<const unsigned short*>(p)[i]) : reinterpret_cast<const float*>(p)[i];
+}
+
+__global__ void __launch_bounds__(OPT_NT) k_sumsq_mt(const ChunkEnt* __restrict__ chunk, const unsigned long long* __restrict__ gptr,
+                                                     int dtype, float* __restrict__ partial) {
+  __shared__ float red[OPT_NT / 64];
+  const ChunkEnt e = chunk[blockIdx.x];
+  const void* g = reinterpret_cast<const void*>(gptr[e.param]);
+  float s = 0.f;
+  if (g != nullptr) {
+    const int nv = e.count & ~7;
+    for (int i = threadIdx.x * OPT_VEC; i < nv; i += OPT_NT * OPT_VEC) {
+      float v[8];
+      load8(g, dtype, (size_t)e.poff + i, v);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) s = __builtin_fmaf(v[k], v[k], s);
+    }
+    for (int i = nv + threadIdx.x; i < e.count; i += OPT_NT) { const float x = ld1(g, dtype, (size_t)e.poff + i); s = __builtin_fmaf(x, x, s); }
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ void __launch_bounds__(OPT_NT) k_adam_mt(const ChunkEnt* __restrict__ chunk, const unsigned long long* __restrict__ gptr,
+                                                    int grad_dtype, float* __restrict__ master, float* __restrict__ m,
+                                                    float* __restrict__ v, unsigned short* __restrict__ shadow, float lr,
+                                                    float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt,
+                                                    const float* __restrict__ clip) {
+  const ChunkEnt e = chunk[blockIdx.x];
+  const void* gp = reinterpret_cast<const void*>(gptr[e.param]);
+  if (gp == nullptr) return;
+  const float c = clip ? clip[1] : 1.f;
+  const float step = lr / bc1;
+  // chunks start 8-aligned in the flat buffers (parameters are padded to 8) and 8-aligned inside the parameter
+  for (int i = threadIdx.x * OPT_VEC; i < e.count; i += OPT_NT * OPT_VEC) {
+    const size_t f = (size_t)e.foff + i;
+    float g[8], p[8], a[8], b[8];
+    if (i + 8 <= e.count) {
+      load8(gp, grad_dtype, (size_t)e.poff + i, g);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) g[k] = i + k < e.count ? ld1(gp, grad_dtype, (size_t)e.poff + i + k) : 0.f;
+    }
+    load8(master, GLR_F32, f, p);
+    load8(m, GLR_F32, f, a);
+    load8(v, GLR_F32, f, b);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const float gk = __builtin_fmaf(wd, p[k], g[k] * c);
+      a[k] = __builtin_fmaf(b1, a[k], (1.f - b1) * gk);
+      b[k] = __builtin_fmaf(b2, b[k], (1.f - b2) * gk * gk);
+      p[k] = p[k] - step * (a[k] / (sqrtf(b[k]) / bc2_sqrt + eps));
+    }
+    *reinterpret_cast<float4*>(master + f) = make_float4(p[0], p[1], p[2], p[3]);
+    *reinterpret_cast<float4*>(master + f + 4) = make_float4(p[4], p[5], p[6], p[7]);
+    *reinterpret_cast<float4*>(m + f) = make_float4(a[0], a[1], a[2], a[3]);
+    *reinterpret_cast<float4*>(m + f + 4) = make_float4(a[4], a[5], a[6], a[7]);
+    *reinterpret_cast<float4*>(v + f) = make_float4(b[0], b[1], b[2], b[3]);
+    *reinterpret_cast<float4*>(v + f + 4) = make_float4(b[4], b[5], b[6], b[7]);
+    if (shadow) {
+      uint4 u;
+      u.x = f2bf(p[0]) | ((unsigned)f2bf(p[1]) << 16);
+      u.y = f2bf(p[2]) | ((unsigned)f2bf(p[3]) << 16);
+      u.z = f2bf(p[4]) | ((unsigned)f2bf(p[5]) << 16);
+      u.w = f2bf(p[6]) | ((unsigned)f2bf(p[7]) << 16);
+      *reinterpret_cast<uint4*>(shadow + f) = u;
+    }
+  }
+}
+
 }  // namespace
+
+extern "C" int glr_sumsq_mt(const void* chunk_table, int n_chunks, const uint64_t* grad_ptrs, int dtype, float* partial,
+                            void* stream) {
+  if (!chunk_table || !grad_ptrs || !partial || n_chunks <= 0) return GLR_EINVAL;
+  if (dtype != GLR_F32 && dtype != GLR_BF16) return GLR_EDTYPE;
+  hipLaunchKernelGGL(k_sumsq_mt, dim3(n_chunks), dim3(OPT_NT), 0, (hipStream_t)stream, (const ChunkEnt*)chunk_table,
+                     (const unsigned long long*)grad_ptrs, dtype, partial);
+  GLR_CHECK_LAUNCH();
+  return GLR_OK;
+}
+
+extern "C" int glr_adam_step_mt(const void* chunk_table, int n_chunks, const uint64_t* grad_ptrs, int grad_dtype,
+                                float* master, float* exp_avg, float* exp_avg_sq, void* shadow_bf16, float lr, float beta1,
+                                float beta2, float eps, float weight_decay, int step, const float* clip, void* stream) {
+  if (!chunk_table || !grad_ptrs || !master || !exp_avg || !exp_avg_sq || n_chunks <= 0 || step < 1) return GLR_EINVAL;
+  if (grad_dtype != GLR_F32 && grad_dtype != GLR_BF16) return GLR_EDTYPE;
+  const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
+  hipLaunchKernelGGL(k_adam_mt, dim3(n_chunks), dim3(OPT_NT), 0, (hipStream_t)stream, (const ChunkEnt*)chunk_table,
+                     (const unsigned long long*)grad_ptrs, grad_dtype, master, exp_avg, exp_avg_sq,
+                     (unsigned short*)shadow_bf16, lr, beta1, beta2, eps, weight_decay, bc1, sqrtf(bc2), clip);
+  GLR_CHECK_LAUNCH();
+  return GLR_OK;
+}
 
 extern "C" int glr_sumsq_blocks(long long n) {
   if (n <= 0) return GLR_EINVAL;

@@ -91,7 +91,8 @@ def build_optimizer(cfg, lr, model):
             skip = {id(p) for p in model.text_encoder.model.pooler.parameters()}
         params = [p for p in params if id(p) not in skip]
         return ShadowAdam(params, lr=lr, betas=(0.5, 0.999), weight_decay=float(cfg.train.optimizer.weight_decay),
-                          max_grad_norm=cfg.train.optimizer.flat_clip, shadow_ids=shadow_parameter_ids(model))
+                          max_grad_norm=cfg.train.optimizer.flat_clip, shadow_ids=shadow_parameter_ids(model),
+                          flat_grads=bool(cfg.train.optimizer.flat_grads))
 
     if cfg.train.optimizer.name == "SGD":
         return torch.optim.SGD(params, lr=lr, momentum=cfg.momentum, weight_decay=cfg.weight_decay)

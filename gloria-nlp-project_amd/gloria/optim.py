@@ -31,9 +31,12 @@ def _storage_flat(t):
     return torch.as_strided(t, (t.numel(),), (1,), t.storage_offset())
 
 
+CHUNK = 16384          # elements per workgroup of the pointer-table kernels
+
+
 class _Group:
-    def __init__(self, params, shadow, device):
-        self.params, self.shadow = params, shadow
+    def __init__(self, params, shadow, device, flat_grads):
+        self.params, self.shadow, self.flat_grads = params, shadow, flat_grads
         self.offsets, off = [], 0
         for p in params:
             self.offsets.append(off)
@@ -43,8 +46,8 @@ class _Group:
         self.master = torch.zeros(self.n, **f32)
         self.exp_avg = torch.zeros(self.n, **f32)
         self.exp_avg_sq = torch.zeros(self.n, **f32)
-        gdt = torch.bfloat16 if shadow else torch.float32
-        self.grad = torch.zeros(self.n, dtype=gdt, device=device)
+        self.gdt = torch.bfloat16 if shadow else torch.float32
+        self.grad = torch.zeros(self.n, dtype=self.gdt, device=device) if flat_grads else None
         self.shadow_buf = torch.zeros(self.n, dtype=torch.bfloat16, device=device) if shadow else None
         for p, o in zip(params, self.offsets):
             k = p.numel()
@@ -54,7 +57,38 @@ class _Group:
                 if shadow:
                     src[o:o + k].copy_(self.master[o:o + k])
                 p.data = src.as_strided(p.shape, p.stride(), storage_offset=o)
-                p.grad = self.grad.as_strided(p.shape, p.stride(), storage_offset=o)
+                p.grad = self.grad.as_strided(p.shape, p.stride(), storage_offset=o) if flat_grads else None
+        if not flat_grads:
+            # static chunk table { param, count, offset in the parameter, offset in the flat buffers } + a pinned
+            # staging buffer for this step's gradient addresses
+            import numpy as np
+            ent = []
+            for i, (p, o) in enumerate(zip(params, self.offsets)):
+                for c0 in range(0, p.numel(), CHUNK):
+                    ent.append((i, min(CHUNK, p.numel() - c0), c0, o + c0))
+            tab = np.zeros(len(ent), dtype=np.dtype([("param", "<i4"), ("count", "<i4"), ("poff", "<i8"), ("foff", "<i8")]))
+            for k, e in enumerate(ent):
+                tab[k] = e
+            self.n_chunks = len(ent)
+            self.table = torch.from_numpy(tab.view(np.uint8).copy()).to(device)
+            self.ptr_host = torch.zeros(len(params), dtype=torch.int64).pin_memory()
+            self.ptr_dev = torch.zeros(len(params), dtype=torch.int64, device=device)
+            self._keep = []
+
+    def stage_grad_pointers(self):
+        """addresses of this step's gradients (dense, parameter strides, group dtype) -> device table"""
+        keep = []
+        for i, p in enumerate(self.params):
+            g = p.grad
+            if g is None:
+                self.ptr_host[i] = 0
+                continue
+            if g.dtype != self.gdt or g.stride() != p.stride():
+                g = torch.empty_strided(p.shape, p.stride(), dtype=self.gdt, device=p.device).copy_(g)
+            keep.append(g)
+            self.ptr_host[i] = g.data_ptr()
+        self._keep = keep                 # alive until the kernels that read them have been queued (same stream)
+        self.ptr_dev.copy_(self.ptr_host, non_blocking=True)
 
     def view(self, buf, i):
         p, o = self.params[i], self.offsets[i]
@@ -64,7 +98,11 @@ class _Group:
 class ShadowAdam(torch.optim.Optimizer):
     """Adam (torch semantics) over flat buffers.  `shadow_ids`: ids of the parameters that become bf16 shadows."""
 
-    def __init__(self, params, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_grad_norm=None, shadow_ids=()):
+    def __init__(self, params, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_grad_norm=None, shadow_ids=(),
+                 flat_grads=False):
+        """flat_grads: every `.grad` is a view of a flat gradient buffer (the data-parallel reducer all-reduces slices
+        of it; autograd then ACCUMULATES into the views: one add launch per parameter).  False (single process): the
+        gradients stay where autograd puts them and the kernels read them through a pointer table."""
         params = [p for p in params if p.requires_grad]
         if not params or not all(p.is_cuda for p in params):
             raise RuntimeError("ShadowAdam runs on GPU parameters (the flat kernels are HIP)")
@@ -74,12 +112,14 @@ class ShadowAdam(torch.optim.Optimizer):
         # reverse registration order: backward produces gradients roughly back to front, so consecutive ranges of a
         # flat buffer complete together (the reducer's buckets)
         rev = list(reversed(params))
-        self.groups = [g for g in (_Group([p for p in rev if id(p) in shadow_ids], True, dev),
-                                   _Group([p for p in rev if id(p) not in shadow_ids], False, dev)) if g.params]
+        self.flat_grads = bool(flat_grads)
+        self.groups = [_Group(pl, sh, dev, self.flat_grads)
+                       for pl, sh in (([p for p in rev if id(p) in shadow_ids], True),
+                                      ([p for p in rev if id(p) not in shadow_ids], False)) if pl]
         self.max_grad_norm = float(max_grad_norm) if max_grad_norm else 0.0
         self.t = 0
         L = N.lib()
-        self._nblocks = [L.glr_sumsq_blocks(g.n) for g in self.groups]
+        self._nblocks = [L.glr_sumsq_blocks(g.n) if self.flat_grads else g.n_chunks for g in self.groups]
         self._partial = torch.zeros(sum(self._nblocks), dtype=torch.float32, device=dev)
         self.clip_state = torch.zeros(2, dtype=torch.float32, device=dev)          # [norm, coefficient] of the last step
         for g in self.groups:                     # per-parameter views of the moments: the stock state_dict layout
@@ -89,6 +129,11 @@ class ShadowAdam(torch.optim.Optimizer):
 
     # ---------------------------------------------------------------- one step
     def zero_grad(self, set_to_none=False):
+        if not self.flat_grads:
+            for g in self.groups:
+                for p in g.params:
+                    p.grad = None
+            return
         for g in self.groups:
             g.grad.zero_()
             for i, p in enumerate(g.params):
@@ -100,17 +145,27 @@ class ShadowAdam(torch.optim.Optimizer):
         L, st = N.lib(), N.stream()
         o = 0
         for g, nb in zip(self.groups, self._nblocks):
-            N.check(L.glr_sumsq_partial(N.ptr(g.grad), N.dtype_code(g.grad.dtype), g.n, N.ptr(self._partial[o:]), st),
-                    "glr_sumsq_partial")
+            if self.flat_grads:
+                N.check(L.glr_sumsq_partial(N.ptr(g.grad), N.dtype_code(g.gdt), g.n, N.ptr(self._partial[o:]), st),
+                        "glr_sumsq_partial")
+            else:
+                g.stage_grad_pointers()
+                N.check(L.glr_sumsq_mt(N.ptr(g.table), g.n_chunks, N.ptr(g.ptr_dev), N.dtype_code(g.gdt),
+                                       N.ptr(self._partial[o:]), st), "glr_sumsq_mt")
             o += nb
         N.check(L.glr_clip_coef(N.ptr(self._partial), o, self.max_grad_norm, N.ptr(self.clip_state), st), "glr_clip_coef")
         self.t += 1
         pg = self.param_groups[0]
+        hyper = (float(pg["lr"]), float(pg["betas"][0]), float(pg["betas"][1]), float(pg["eps"]),
+                 float(pg["weight_decay"]), self.t, N.ptr(self.clip_state), st)
         for g in self.groups:
-            N.check(L.glr_adam_step(N.ptr(g.master), N.ptr(g.exp_avg), N.ptr(g.exp_avg_sq), N.ptr(g.grad),
-                                    N.dtype_code(g.grad.dtype), N.ptr(g.shadow_buf), g.n, float(pg["lr"]),
-                                    float(pg["betas"][0]), float(pg["betas"][1]), float(pg["eps"]),
-                                    float(pg["weight_decay"]), self.t, N.ptr(self.clip_state), st), "glr_adam_step")
+            if self.flat_grads:
+                N.check(L.glr_adam_step(N.ptr(g.master), N.ptr(g.exp_avg), N.ptr(g.exp_avg_sq), N.ptr(g.grad),
+                                        N.dtype_code(g.gdt), N.ptr(g.shadow_buf), g.n, *hyper), "glr_adam_step")
+            else:
+                N.check(L.glr_adam_step_mt(N.ptr(g.table), g.n_chunks, N.ptr(g.ptr_dev), N.dtype_code(g.gdt),
+                                           N.ptr(g.master), N.ptr(g.exp_avg), N.ptr(g.exp_avg_sq), N.ptr(g.shadow_buf),
+                                           *hyper), "glr_adam_step_mt")
         for s in self.state.values():
             s["step"] = torch.tensor(float(self.t))
 

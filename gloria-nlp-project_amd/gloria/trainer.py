@@ -52,6 +52,9 @@ class Trainer:
         if self.flat_optimizer:
             self.cfg.set_path("train.optimizer.flat_bf16", True)
             self.cfg.set_path("train.optimizer.flat_clip", self.clip)
+            # data-parallel ranks need every gradient inside a flat bucket (all-reduced slice by slice during
+            # backward); a single process reads the gradients where autograd leaves them (pointer table)
+            self.cfg.set_path("train.optimizer.flat_grads", bool(self.dist is not None and self.dist.active))
         opt = model.configure_optimizers()
         self.optimizer, self.scheduler = opt["optimizer"], opt["lr_scheduler"]
         self.params = [p for g in self.optimizer.param_groups for p in g["params"]]

@@ -342,6 +342,16 @@ int glr_collate_images(const void* src, const int64_t* offset, const int32_t* de
  *                       (sqrt(v) / sqrt(1 - b2^step) + eps); writes the bf16 shadow of p when shadow_bf16 != NULL.
  *                       clip may be NULL (no clipping).
  */
+/* Pointer-table forms (single process: gradients stay one tensor per parameter, nothing is accumulated into a flat
+ * buffer).  chunk_table: device array of { int32 param, int32 count, int64 offset in the parameter, int64 offset in
+ * the flat buffers } (24 bytes, count <= 16384, both offsets multiples of 8), one workgroup per entry;
+ * grad_ptrs[param]: device address of that parameter's gradient this step, 0 = no gradient (parameter skipped, as
+ * torch.optim.Adam skips None).  glr_sumsq_mt writes one partial per chunk. */
+int glr_sumsq_mt(const void* chunk_table, int n_chunks, const uint64_t* grad_ptrs, int dtype, float* partial,
+                 void* stream);
+int glr_adam_step_mt(const void* chunk_table, int n_chunks, const uint64_t* grad_ptrs, int grad_dtype, float* master,
+                     float* exp_avg, float* exp_avg_sq, void* shadow_bf16, float lr, float beta1, float beta2, float eps,
+                     float weight_decay, int step, const float* clip, void* stream);
 int glr_sumsq_blocks(long long n);
 int glr_sumsq_partial(const void* x, int dtype, long long n, float* partial, void* stream);
 int glr_clip_coef(const float* partial, int n_partial, float max_norm, float* out, void* stream);

@@ -149,7 +149,8 @@ def _toy(seed=0):
     return m
 
 
-def test_flat_adam_matches_torch_adam_with_clipping():
+@pytest.mark.parametrize("flat_grads", [True, False])
+def test_flat_adam_matches_torch_adam_with_clipping(flat_grads):
     """gloria.optim.ShadowAdam (flat fp32 masters, bf16 shadows, clip folded in: three launches) against
     torch.optim.Adam + clip_grad_norm_ fed the SAME gradients, 4 steps: masters, moments and the clip norm agree;
     shadows are bf16(master); parameters of normalisation layers stay fp32."""
@@ -160,7 +161,7 @@ def test_flat_adam_matches_torch_adam_with_clipping():
     b.conv.to(memory_format=torch.channels_last)
     pa, pb = list(a.parameters()), list(b.parameters())
     opt = ShadowAdam(pa, lr=1e-2, betas=(0.5, 0.999), weight_decay=1e-3, max_grad_norm=0.25,
-                     shadow_ids=shadow_parameter_ids(a))
+                     shadow_ids=shadow_parameter_ids(a), flat_grads=flat_grads)
     ref = torch.optim.Adam(pb, lr=1e-2, betas=(0.5, 0.999), weight_decay=1e-3)
     assert a.fc1.weight.dtype == torch.bfloat16 and a.fc1.bias.dtype == torch.bfloat16 and a.emb.weight.dtype == torch.float32
     assert a.ln.weight.dtype == torch.float32 and a.bn.weight.dtype == torch.float32 and a.free.dtype == torch.float32
@@ -170,7 +171,10 @@ def test_flat_adam_matches_torch_adam_with_clipping():
         for p, q in zip(pa, pb):
             grad = torch.randn(q.shape, device=dev, generator=g) * (0.3 if step % 2 else 3.0)
             grad = grad.to(p.dtype)                     # what autograd hands a bf16 / fp32 parameter
-            p.grad.copy_(grad)
+            if flat_grads:
+                p.grad.copy_(grad)                      # data-parallel mode: views of the flat bucket
+            else:                                       # single process: a tensor per parameter, read by pointer
+                p.grad = torch.empty_strided(p.shape, p.stride(), dtype=p.dtype, device=dev).copy_(grad)
             q.grad = grad.float().contiguous(memory_format=torch.channels_last) if q.dim() == 4 else grad.float()
         norm = torch.nn.utils.clip_grad_norm_(pb, 0.25)
         ref.step()
