@@ -148,6 +148,10 @@ def cpu_baseline(sample_batch=16, full=False):
 
 
 def main():
+    # the contract is ONE JSON line on stdout: libraries that print to fd 1 (RCCL's version banner at communicator
+    # creation) are sent to stderr, the line itself goes to the saved descriptor
+    out_fd = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -274,7 +278,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             # free the GPU-side model first; the CPU leg builds its own copy
             rec["cpu_baseline"] = cpu_baseline(full=args.cpu_full)
-        print(json.dumps(rec), flush=True)
+        os.write(out_fd, (json.dumps(rec) + "\n").encode())
     if dctx:
         dctx.barrier()
         torch.distributed.destroy_process_group()

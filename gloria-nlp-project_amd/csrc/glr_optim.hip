@@ -184,7 +184,36 @@ __global__ void __launch_bounds__(OPT_NT) k_adam_mt(const ChunkEnt* __restrict__
   }
 }
 
+// gather: the gradients of a bucket's parameters (one tensor each) -> their slots of the flat gradient buffer, one
+// launch per bucket (data-parallel: the bucket is then all-reduced as one slice)
+__global__ void __launch_bounds__(OPT_NT) k_gather_mt(const ChunkEnt* __restrict__ chunk, const unsigned long long* __restrict__ gptr,
+                                                      int dtype, void* __restrict__ flat) {
+  const ChunkEnt e = chunk[blockIdx.x];
+  const void* g = reinterpret_cast<const void*>(gptr[e.param]);
+  if (g == nullptr) return;                        // the slot keeps the zeros of zero_grad
+  const int esz = dtype == GLR_BF16 ? 2 : 4, per16 = 16 / esz;
+  const unsigned char* src = reinterpret_cast<const unsigned char*>(g) + (size_t)e.poff * esz;
+  unsigned char* dst = reinterpret_cast<unsigned char*>(flat) + (size_t)e.foff * esz;
+  const int nv = e.count / per16;
+  for (int i = threadIdx.x; i < nv; i += OPT_NT)
+    reinterpret_cast<uint4*>(dst)[i] = reinterpret_cast<const uint4*>(src)[i];
+  for (int i = nv * per16 + threadIdx.x; i < e.count; i += OPT_NT) {
+    if (esz == 2) reinterpret_cast<unsigned short*>(dst)[i] = reinterpret_cast<const unsigned short*>(src)[i];
+    else reinterpret_cast<float*>(dst)[i] = reinterpret_cast<const float*>(src)[i];
+  }
+}
+
 }  // namespace
+
+extern "C" int glr_gather_mt(const void* chunk_table, int n_chunks, const uint64_t* grad_ptrs, int dtype, void* flat,
+                             void* stream) {
+  if (!chunk_table || !grad_ptrs || !flat || n_chunks <= 0) return GLR_EINVAL;
+  if (dtype != GLR_F32 && dtype != GLR_BF16) return GLR_EDTYPE;
+  hipLaunchKernelGGL(k_gather_mt, dim3(n_chunks), dim3(OPT_NT), 0, (hipStream_t)stream, (const ChunkEnt*)chunk_table,
+                     (const unsigned long long*)grad_ptrs, dtype, flat);
+  GLR_CHECK_LAUNCH();
+  return GLR_OK;
+}
 
 extern "C" int glr_sumsq_mt(const void* chunk_table, int n_chunks, const uint64_t* grad_ptrs, int dtype, float* partial,
                             void* stream) {

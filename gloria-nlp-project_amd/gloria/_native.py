@@ -41,6 +41,7 @@ SYMBOLS = {
                                    # sim, dsim, ld, lse, wstat, damean, dattn, attn_off, strip, img_offset,
                                    # xout, aout, gamma, beta, dtype, stream
     "glr_sumsq_blocks": (c_int, [ctypes.c_longlong]),
+    "glr_gather_mt": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p]),
     "glr_sumsq_mt": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p]),
     "glr_adam_step_mt": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float,
                                  c_float, c_float, c_float, c_int, c_void_p, c_void_p]),

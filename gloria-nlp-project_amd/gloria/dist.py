@@ -45,8 +45,9 @@ class _AllGatherGrad(torch.autograd.Function):
 
 
 class DistContext:
-    def __init__(self, group=None):
+    def __init__(self, group=None, cpu_group=None):
         self.group = group
+        self.cpu_group = cpu_group        # gloo group for host-side integers (caption lengths): no device round trip
         self.rank = dist.get_rank(group)
         self.world_size = dist.get_world_size(group)
         # GLR_FORCE_DIST=1 runs the sharded code path (all-gather / reduce-scatter / bucketed all-reduce)
@@ -64,7 +65,14 @@ class DistContext:
         return out
 
     def all_gather_ints(self, values):
-        """host int lists of equal length per rank -> concatenated host list (one small collective)."""
+        """host int lists of equal length per rank -> concatenated host list (one small collective).  With a gloo
+        side group the integers never touch the GPU: a device collective would need a D2H copy and a stream sync per
+        step before the host can plan the word tiles, draining the queue the encoders were launched into."""
+        if self.cpu_group is not None:
+            t = torch.tensor(list(values), dtype=torch.int32)
+            out = torch.empty(self.world_size * t.numel(), dtype=torch.int32)
+            dist.all_gather_into_tensor(out, t, group=self.cpu_group)
+            return out.tolist()
         dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(self.group) == "nccl" else "cpu"
         t = torch.tensor(list(values), dtype=torch.int32, device=dev)
         out = torch.empty(self.world_size * t.numel(), dtype=torch.int32, device=dev)
@@ -124,28 +132,41 @@ class GradReducer:
 
     @classmethod
     def from_flat(cls, groups, ctx, bucket_bytes=64 << 20):
-        """groups: [(flat gradient buffer, [params in buffer order], [element offsets])] of a flat optimizer
-        (gloria.optim.ShadowAdam) whose `.grad`s already are views of those buffers.  Buckets are consecutive
-        parameter ranges of a buffer (>= bucket_bytes each), all-reduced as slices: nothing is copied or re-laid."""
+        """groups: the parameter groups of a flat optimizer (gloria.optim.ShadowAdam, flat_grads=True).  A bucket is a
+        run of consecutive parameters of one group (>= bucket_bytes of gradient); when its last gradient arrives the
+        group gathers the bucket's gradients into the flat buffer with ONE launch (`group.gather`) and the slice is
+        all-reduced asynchronously while backward keeps running."""
         self = cls.__new__(cls)
         self.ctx, self.buckets, self._views, self._fired = ctx, [], {}, set()
-        self._hide_unused = False         # every parameter of a flat optimizer is stepped: its zero gradient is real
-        for flat, plist, offs in groups:
-            start, cur = 0, []
-            for i, p in enumerate(plist):
-                cur.append(p)
-                end = offs[i + 1] if i + 1 < len(plist) else flat.numel()
-                if (end - offs[start]) * flat.element_size() >= bucket_bytes or i + 1 == len(plist):
+        self._hide_unused = False
+        self._flat = []                   # per bucket: (group, first parameter, one past the last)
+        for g in groups:
+            esz = 2 if g.gdt == torch.bfloat16 else 4
+            start = 0
+            for i in range(len(g.params)):
+                end_off = g.offsets[i + 1] if i + 1 < len(g.params) else g.n
+                if (end_off - g.offsets[start]) * esz >= bucket_bytes or i + 1 == len(g.params):
                     idx = len(self.buckets)
-                    self.buckets.append((flat[offs[start]:end], cur))
-                    for q in cur:
-                        self._views[q] = q.grad
+                    plist = g.params[start:i + 1]
+                    self.buckets.append((None, plist))
+                    self._flat.append((g, start, i + 1))
+                    for q in plist:
                         q.register_post_accumulate_grad_hook(lambda _p, k=idx: self._on_ready(k, _p))
-                    start, cur = i + 1, []
+                    start = i + 1
         self._pending = []
         self._ready = [0] * len(self.buckets)
+        self._done = [False] * len(self.buckets)
         self._open = False
         return self
+
+    def _reduce_bucket(self, i):
+        if getattr(self, "_flat", None):
+            g, i0, i1 = self._flat[i]
+            buf = g.gather(i0, i1)
+            self._done[i] = True
+        else:
+            buf = self.buckets[i][0]
+        self._pending.append(dist.all_reduce(buf, group=self.ctx.group, async_op=True))
 
     def __init__(self, params, ctx, bucket_bytes=64 << 20):
         self.ctx = ctx
@@ -184,10 +205,17 @@ class GradReducer:
         self.buckets.append((flat, plist))
 
     def zero_grad(self):
-        for flat, plist in self.buckets:
-            flat.zero_()
-            for p in plist:
-                p.grad = self._views[p]           # re-attach: finish() hides the views of unused parameters
+        if getattr(self, "_flat", None):
+            for g in {id(f[0]): f[0] for f in self._flat}.values():
+                g.grad.zero_()
+                for p in g.params:
+                    p.grad = None
+            self._done = [False] * len(self.buckets)
+        else:
+            for flat, plist in self.buckets:
+                flat.zero_()
+                for p in plist:
+                    p.grad = self._views[p]       # re-attach: finish() hides the views of unused parameters
         self._ready = [0] * len(self.buckets)
         self._pending = []
         self._fired = set()
@@ -200,13 +228,13 @@ class GradReducer:
         self._fired.add(p)
         self._ready[i] += 1
         if self._ready[i] == len(self.buckets[i][1]):
-            self._pending.append(dist.all_reduce(self.buckets[i][0], group=self.ctx.group, async_op=True))
+            self._reduce_bucket(i)
 
     def finish(self):
         # parameters that received no gradient this step leave their bucket incomplete: reduce it now
         for i, (flat, plist) in enumerate(self.buckets):
             if self._ready[i] != len(plist):
-                self._pending.append(dist.all_reduce(flat, group=self.ctx.group, async_op=True))
+                self._reduce_bucket(i)
         for w in self._pending:
             w.wait()
         self._pending = []
@@ -240,4 +268,10 @@ def init_from_env(backend=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group(backend=backend)
-    return DistContext()
+    cpu_group = None
+    if dist.get_backend() == "nccl":
+        try:
+            cpu_group = dist.new_group(backend="gloo")
+        except Exception:          # noqa: BLE001 - gloo unavailable: fall back to the device collective
+            cpu_group = None
+    return DistContext(cpu_group=cpu_group)

@@ -57,38 +57,66 @@ class _Group:
                 if shadow:
                     src[o:o + k].copy_(self.master[o:o + k])
                 p.data = src.as_strided(p.shape, p.stride(), storage_offset=o)
-                p.grad = self.grad.as_strided(p.shape, p.stride(), storage_offset=o) if flat_grads else None
-        if not flat_grads:
-            # static chunk table { param, count, offset in the parameter, offset in the flat buffers } + a pinned
-            # staging buffer for this step's gradient addresses
-            import numpy as np
-            ent = []
-            for i, (p, o) in enumerate(zip(params, self.offsets)):
-                for c0 in range(0, p.numel(), CHUNK):
-                    ent.append((i, min(CHUNK, p.numel() - c0), c0, o + c0))
-            tab = np.zeros(len(ent), dtype=np.dtype([("param", "<i4"), ("count", "<i4"), ("poff", "<i8"), ("foff", "<i8")]))
-            for k, e in enumerate(ent):
-                tab[k] = e
-            self.n_chunks = len(ent)
-            self.table = torch.from_numpy(tab.view(np.uint8).copy()).to(device)
-            self.ptr_host = torch.zeros(len(params), dtype=torch.int64).pin_memory()
-            self.ptr_dev = torch.zeros(len(params), dtype=torch.int64, device=device)
-            self._keep = []
+                p.grad = None
+        # static chunk table { param, count, offset in the parameter, offset in the flat buffers } + a pinned staging
+        # buffer for this step's gradient addresses (gradients stay one tensor per parameter, as autograd leaves them)
+        import numpy as np
+        ent, self.chunk_start = [], []
+        for i, (p, o) in enumerate(zip(params, self.offsets)):
+            self.chunk_start.append(len(ent))
+            for c0 in range(0, p.numel(), CHUNK):
+                ent.append((i, min(CHUNK, p.numel() - c0), c0, o + c0))
+        self.chunk_start.append(len(ent))
+        tab = np.zeros(len(ent), dtype=np.dtype([("param", "<i4"), ("count", "<i4"), ("poff", "<i8"), ("foff", "<i8")]))
+        for k, e in enumerate(ent):
+            tab[k] = e
+        self.n_chunks = len(ent)
+        self.table = torch.from_numpy(tab.view(np.uint8).copy()).to(device)
+        # two pinned staging buffers used alternately + an event: the host may not rewrite a buffer whose
+        # asynchronous upload has not run yet
+        self.ptr_host2 = [torch.zeros(len(params), dtype=torch.int64).pin_memory() for _ in range(2)]
+        self.ptr_event = [None, None]
+        self.ptr_turn = 0
+        self.ptr_dev = torch.zeros(len(params), dtype=torch.int64, device=device)
+        self._keep = []
 
-    def stage_grad_pointers(self):
-        """addresses of this step's gradients (dense, parameter strides, group dtype) -> device table"""
+    def stage_grad_pointers(self, i0=0, i1=None):
+        """addresses of this step's gradients of parameters [i0, i1) (dense, parameter strides, group dtype) -> device"""
+        i1 = len(self.params) if i1 is None else i1
+        turn = self.ptr_turn
+        self.ptr_turn ^= 1
+        if self.ptr_event[turn] is not None:
+            self.ptr_event[turn].synchronize()        # the upload that last used this staging buffer has run
+        host = self.ptr_host2[turn]
         keep = []
-        for i, p in enumerate(self.params):
+        for i in range(i0, i1):
+            p = self.params[i]
             g = p.grad
             if g is None:
-                self.ptr_host[i] = 0
+                host[i] = 0
                 continue
             if g.dtype != self.gdt or g.stride() != p.stride():
                 g = torch.empty_strided(p.shape, p.stride(), dtype=self.gdt, device=p.device).copy_(g)
             keep.append(g)
-            self.ptr_host[i] = g.data_ptr()
+            host[i] = g.data_ptr()
         self._keep = keep                 # alive until the kernels that read them have been queued (same stream)
-        self.ptr_dev.copy_(self.ptr_host, non_blocking=True)
+        self.ptr_dev[i0:i1].copy_(host[i0:i1], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self.ptr_event[turn] = ev
+
+    def gather(self, i0, i1):
+        """data-parallel: the gradients of parameters [i0, i1) -> their slots of the flat gradient buffer (one launch),
+        then released; returns the slice of the flat buffer that holds them (an all-reduce bucket)"""
+        self.stage_grad_pointers(i0, i1)
+        c0, c1 = self.chunk_start[i0], self.chunk_start[i1]
+        rec = 24                          # bytes per chunk-table entry
+        N.check(N.lib().glr_gather_mt(N.ptr(self.table[c0 * rec:]), c1 - c0, N.ptr(self.ptr_dev), N.dtype_code(self.gdt),
+                                      N.ptr(self.grad), N.stream()), "glr_gather_mt")
+        for i in range(i0, i1):
+            self.params[i].grad = None
+        end = self.offsets[i1] if i1 < len(self.params) else self.n
+        return self.grad[self.offsets[i0]:end]
 
     def view(self, buf, i):
         p, o = self.params[i], self.offsets[i]
@@ -100,9 +128,11 @@ class ShadowAdam(torch.optim.Optimizer):
 
     def __init__(self, params, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_grad_norm=None, shadow_ids=(),
                  flat_grads=False):
-        """flat_grads: every `.grad` is a view of a flat gradient buffer (the data-parallel reducer all-reduces slices
-        of it; autograd then ACCUMULATES into the views: one add launch per parameter).  False (single process): the
-        gradients stay where autograd puts them and the kernels read them through a pointer table."""
+        """Gradients always stay where autograd puts them (one tensor per parameter: making `.grad` a view of a flat
+        buffer costs an accumulation launch per parameter).  flat_grads=False (single process): the norm / Adam kernels
+        read them through a pointer table.  flat_grads=True (data parallel): the reducer gathers every bucket's
+        gradients into a flat buffer with one launch when its last gradient arrives (`_Group.gather`), all-reduces
+        that slice, and the kernels read the flat buffer."""
         params = [p for p in params if p.requires_grad]
         if not params or not all(p.is_cuda for p in params):
             raise RuntimeError("ShadowAdam runs on GPU parameters (the flat kernels are HIP)")
@@ -129,16 +159,11 @@ class ShadowAdam(torch.optim.Optimizer):
 
     # ---------------------------------------------------------------- one step
     def zero_grad(self, set_to_none=False):
-        if not self.flat_grads:
-            for g in self.groups:
-                for p in g.params:
-                    p.grad = None
-            return
         for g in self.groups:
-            g.grad.zero_()
-            for i, p in enumerate(g.params):
-                if p.grad is None or p.grad.data_ptr() != g.grad.data_ptr() + g.offsets[i] * g.grad.element_size():
-                    p.grad = g.view(g.grad, i)
+            if self.flat_grads:
+                g.grad.zero_()            # slots of parameters without a gradient (and the padding) read as zero
+            for p in g.params:
+                p.grad = None
 
     @torch.no_grad()
     def step(self, closure=None):

@@ -52,7 +52,7 @@ class Trainer:
         if self.flat_optimizer:
             self.cfg.set_path("train.optimizer.flat_bf16", True)
             self.cfg.set_path("train.optimizer.flat_clip", self.clip)
-            # data-parallel ranks need every gradient inside a flat bucket (all-reduced slice by slice during
+            # data-parallel ranks gather every bucket's gradients into a flat buffer (all-reduced slice by slice during
             # backward); a single process reads the gradients where autograd leaves them (pointer table)
             self.cfg.set_path("train.optimizer.flat_grads", bool(self.dist is not None and self.dist.active))
         opt = model.configure_optimizers()
@@ -64,7 +64,7 @@ class Trainer:
         if self.dist is not None and self.dist.active:
             from .dist import GradReducer
             if self.flat:       # the optimizer's flat gradient buffers are the all-reduce buckets
-                self.reducer = GradReducer.from_flat([(g.grad, g.params, g.offsets) for g in self.optimizer.groups], self.dist)
+                self.reducer = GradReducer.from_flat(self.optimizer.groups, self.dist)
             else:
                 self.reducer = GradReducer(self.params, self.dist)      # grads become views of flat buckets
         return model

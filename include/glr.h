@@ -347,6 +347,10 @@ int glr_collate_images(const void* src, const int64_t* offset, const int32_t* de
  * the flat buffers } (24 bytes, count <= 16384, both offsets multiples of 8), one workgroup per entry;
  * grad_ptrs[param]: device address of that parameter's gradient this step, 0 = no gradient (parameter skipped, as
  * torch.optim.Adam skips None).  glr_sumsq_mt writes one partial per chunk. */
+/* glr_gather_mt: copy the gradients named by (a range of) the chunk table into their slots of the flat gradient buffer
+ * `flat` (element offsets = the table's flat offsets), one launch: how a data-parallel rank fills an all-reduce bucket
+ * when the bucket's last gradient has arrived. */
+int glr_gather_mt(const void* chunk_table, int n_chunks, const uint64_t* grad_ptrs, int dtype, void* flat, void* stream);
 int glr_sumsq_mt(const void* chunk_table, int n_chunks, const uint64_t* grad_ptrs, int dtype, float* partial,
                  void* stream);
 int glr_adam_step_mt(const void* chunk_table, int n_chunks, const uint64_t* grad_ptrs, int grad_dtype, float* master,

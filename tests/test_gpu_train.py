@@ -171,11 +171,13 @@ def test_flat_adam_matches_torch_adam_with_clipping(flat_grads):
         for p, q in zip(pa, pb):
             grad = torch.randn(q.shape, device=dev, generator=g) * (0.3 if step % 2 else 3.0)
             grad = grad.to(p.dtype)                     # what autograd hands a bf16 / fp32 parameter
-            if flat_grads:
-                p.grad.copy_(grad)                      # data-parallel mode: views of the flat bucket
-            else:                                       # single process: a tensor per parameter, read by pointer
-                p.grad = torch.empty_strided(p.shape, p.stride(), dtype=p.dtype, device=dev).copy_(grad)
+            p.grad = torch.empty_strided(p.shape, p.stride(), dtype=p.dtype, device=dev).copy_(grad)
             q.grad = grad.float().contiguous(memory_format=torch.channels_last) if q.dim() == 4 else grad.float()
+        if flat_grads:                                  # data-parallel mode: buckets gathered into the flat buffer
+            for grp in opt.groups:
+                half = len(grp.params) // 2
+                grp.gather(0, half)
+                grp.gather(half, len(grp.params))
         norm = torch.nn.utils.clip_grad_norm_(pb, 0.25)
         ref.step()
         opt.step()
