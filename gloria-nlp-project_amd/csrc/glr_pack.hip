@@ -203,6 +203,28 @@ __global__ void __launch_bounds__(256) k_pack_regions(const void* __restrict__ i
     st_any(vt, ((size_t)b * S_pad + r0 + rl) * D + d0 + tx, op_dtype, tile[tx][rl]);
 }
 
+// Fast path of the training step: channels-last bf16 features -> bf16 operands.  One thread moves 16 bytes
+// (8 features of one region) and writes them TWICE: row-major vt (the gradient GEMMs' operand) and the K-tiled
+// copy the K1 streams read ([D*2 / 64][S_pad][64 bytes] per image) - one read of the features instead of a pack
+// pass plus a tiling pass.  Rows [S_eff, S_pad) are zero, the optional no-attention vector is row 0.
+__global__ void __launch_bounds__(256) k_pack_regions_cl16(const uint4* __restrict__ img, const uint4* __restrict__ no_attn,
+                                                           uint4* __restrict__ vt, uint4* __restrict__ vt_t, int D16,
+                                                           int S, int S_pad, int shift, size_t total) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;       // index of a 16-byte piece of vt
+  if (i >= total) return;
+  const int c = (int)(i % D16);                   // 16-byte piece inside the row
+  const size_t row = i / D16;
+  const int rp = (int)(row % S_pad);
+  const size_t b = row / S_pad;
+  uint4 v = make_uint4(0u, 0u, 0u, 0u);
+  if (rp < S + shift) v = (shift && rp == 0) ? no_attn[c] : img[(b * S + (rp - shift)) * D16 + c];
+  vt[i] = v;
+  if (vt_t) {
+    const int nch = D16 / 4;                      // 64-byte chunks per row
+    vt_t[((b * nch + (c >> 2)) * S_pad + rp) * 4 + (c & 3)] = v;
+  }
+}
+
 // grid (D/64, B_txt), 256 threads
 __global__ void __launch_bounds__(256) k_pack_words(const void* __restrict__ words, int in_dtype,
                                                     const int* __restrict__ sent_slot0,
@@ -247,7 +269,10 @@ __global__ void __launch_bounds__(256) k_word_norms(const void* __restrict__ tp,
 
 // K-tiling copy: every block of `rows` rows x `row_bytes` bytes is rewritten as [row_bytes / 64][rows][64 B],
 // so that the K1 streams read 1-KiB contiguous pieces.  One thread moves 16 bytes; writes are linear.
-__global__ void k_tile_k(const uint4* __restrict__ src, uint4* __restrict__ dst, int rows, int nch, size_t total) {
+// ones_row >= 0: row `ones_row` of every block is written as ones_cols elements of 1.0 (element size esz) followed
+// by zeros instead of being copied - the Gram operand's ones row (glr_local_attn_fwd, tile_rowflags).
+__global__ void k_tile_k(const uint4* __restrict__ src, uint4* __restrict__ dst, int rows, int nch, size_t total,
+                         int ones_row, int ones_cols, int esz) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
   const int s16 = (int)(i & 3);
@@ -256,33 +281,80 @@ __global__ void k_tile_k(const uint4* __restrict__ src, uint4* __restrict__ dst,
   const size_t u = t / rows;
   const int c = (int)(u % nch);
   const size_t blk = u / nch;
-  dst[i] = src[((blk * rows + r) * nch + c) * 4 + s16];
+  uint4 v = src[((blk * rows + r) * nch + c) * 4 + s16];
+  if (r == ones_row) {
+    const int per = 16 / esz;                     // elements per 16-byte piece
+    const int e0 = (c * 4 + s16) * per;           // first element (column) of this piece
+    unsigned w[4] = {0u, 0u, 0u, 0u};
+    for (int k = 0; k < per; ++k) {
+      if (e0 + k >= ones_cols) break;
+      if (esz == 2) w[k >> 1] |= 0x3f80u << (16 * (k & 1));       // bf16 1.0
+      else w[k] = 0x3f800000u;                                     // fp32 1.0
+    }
+    v = make_uint4(w[0], w[1], w[2], w[3]);
+  }
+  dst[i] = v;
 }
 
 }  // namespace
 
-extern "C" int glr_tile_k(const void* src, void* dst, int rows, long long n_blocks, int row_bytes, void* stream) {
+static int tile_k_impl(const void* src, void* dst, int rows, long long n_blocks, int row_bytes, int ones_row, int ones_cols,
+                       int esz, void* stream) {
   if (!src || !dst || rows <= 0 || n_blocks <= 0 || row_bytes <= 0 || row_bytes % 64 != 0) return GLR_EINVAL;
   const size_t total = (size_t)n_blocks * rows * (row_bytes / 16);
   const int nch = row_bytes / 64;
   hipLaunchKernelGGL(k_tile_k, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                     (const uint4*)src, (uint4*)dst, rows, nch, total);
+                     (const uint4*)src, (uint4*)dst, rows, nch, total, ones_row, ones_cols, esz);
   GLR_CHECK_LAUNCH();
   return GLR_OK;
 }
 
-extern "C" int glr_pack_regions(const void* img_features, int in_dtype, int in_layout, const void* no_attn_vec,
-                                void* vt, int B, int D, int S, int op_dtype, void* stream) {
+extern "C" int glr_tile_k(const void* src, void* dst, int rows, long long n_blocks, int row_bytes, void* stream) {
+  return tile_k_impl(src, dst, rows, n_blocks, row_bytes, -1, 0, 2, stream);
+}
+
+extern "C" int glr_tile_gram(const void* gram, void* gram_t, int S_pad, long long B, int S_eff, int op_dtype, void* stream) {
+  if (op_dtype != GLR_F32 && op_dtype != GLR_BF16) return GLR_EDTYPE;
+  if (S_eff <= 0 || S_eff > S_pad) return GLR_EINVAL;
+  const int esz = op_dtype == GLR_F32 ? 4 : 2;
+  return tile_k_impl(gram, gram_t, S_pad, B, S_pad * esz, S_eff < S_pad ? S_pad - 1 : -1, S_eff, esz, stream);
+}
+
+static int pack_regions_impl(const void* img_features, int in_dtype, int in_layout, const void* no_attn_vec, void* vt,
+                             void* vt_t, int B, int D, int S, int op_dtype, void* stream) {
   if (!img_features || !vt || B <= 0 || D <= 0 || S <= 0 || D % 64 != 0) return GLR_EINVAL;
   if (in_layout != 0 && in_layout != 1) return GLR_EINVAL;
   if ((in_dtype != GLR_F32 && in_dtype != GLR_BF16) || (op_dtype != GLR_F32 && op_dtype != GLR_BF16)) return GLR_EDTYPE;
   const int shift = no_attn_vec ? 1 : 0;
   const int S_pad = glr_region_pad(S + shift);
   if (S_pad > GLR_MAX_SPAD) return GLR_EINVAL;
+  const bool aligned = ((uintptr_t)img_features % 16 == 0) && (!no_attn_vec || (uintptr_t)no_attn_vec % 16 == 0);
+  if (in_layout == 1 && in_dtype == GLR_BF16 && op_dtype == GLR_BF16 && aligned) {
+    // the training step's case: one 16-byte-per-thread pass that also emits the K-tiled copy
+    const int D16 = D * 2 / 16;
+    const size_t total = (size_t)B * S_pad * D16;
+    hipLaunchKernelGGL(k_pack_regions_cl16, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const uint4*)img_features, (const uint4*)no_attn_vec, (uint4*)vt, (uint4*)vt_t, D16, S, S_pad, shift,
+                       total);
+    GLR_CHECK_LAUNCH();
+    return GLR_OK;
+  }
   hipLaunchKernelGGL(k_pack_regions, dim3(S_pad / 64, D / 64, B), dim3(256), 0, (hipStream_t)stream, img_features,
                      in_dtype, in_layout, no_attn_vec, vt, D, S, S_pad, shift, op_dtype);
   GLR_CHECK_LAUNCH();
+  if (vt_t) return glr_tile_k(vt, vt_t, S_pad, B, D * (op_dtype == GLR_F32 ? 4 : 2), stream);
   return GLR_OK;
+}
+
+extern "C" int glr_pack_regions(const void* img_features, int in_dtype, int in_layout, const void* no_attn_vec,
+                                void* vt, int B, int D, int S, int op_dtype, void* stream) {
+  return pack_regions_impl(img_features, in_dtype, in_layout, no_attn_vec, vt, nullptr, B, D, S, op_dtype, stream);
+}
+
+extern "C" int glr_pack_regions_tiled(const void* img_features, int in_dtype, int in_layout, const void* no_attn_vec,
+                                      void* vt, void* vt_t, int B, int D, int S, int op_dtype, void* stream) {
+  if (!vt_t) return GLR_EINVAL;
+  return pack_regions_impl(img_features, in_dtype, in_layout, no_attn_vec, vt, vt_t, B, D, S, op_dtype, stream);
 }
 
 extern "C" int glr_pack_words(const void* words_emb, int in_dtype, const int32_t* sent_slot0_dev,

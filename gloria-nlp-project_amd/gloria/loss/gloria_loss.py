@@ -114,25 +114,23 @@ def _pack_operands(img_features, words, no_attn_vec, cap_lens, o):
     words = words.contiguous()
     na = None if no_attn_vec is None else no_attn_vec.detach().to(img.dtype).contiguous()
     st = N.stream()
+    # K1 streams the K-tiled copies (contiguous 1-KiB DMA pieces); the row-major vt / tp stay for the gradient GEMMs
     vt = torch.empty(B, s_pad, D, dtype=odt, device=dev)
-    N.check(L.glr_pack_regions(N.ptr(img), in_code, layout, N.ptr(na), N.ptr(vt), B, D, S, code, st),
-            "glr_pack_regions")
+    vt_t = torch.empty_like(vt)
+    N.check(L.glr_pack_regions_tiled(N.ptr(img), in_code, layout, N.ptr(na), N.ptr(vt), N.ptr(vt_t), B, D, S, code, st),
+            "glr_pack_regions_tiled")
     gram = torch.bmm(vt, vt.transpose(1, 2))            # plain batched GEMM (hipBLASLt): G[b] = V^T V
-    if s_eff < s_pad:
-        # ones in a padded row: the forward pair kernel reads Z_w = sum_r e2[w, r] out of the second contraction
-        # (include/glr.h, tile_rowflags); every kernel masks padded regions, so nothing else sees the row
-        gram[:, s_pad - 1, :s_eff] = 1.0
+    gram_t = torch.empty_like(gram)
+    # tiling + the ones row (a padded region) out of which the forward pair kernel reads Z_w = sum_r e2[w, r]
+    # (include/glr.h, tile_rowflags); every kernel masks padded regions, so nothing else sees the row
+    N.check(L.glr_tile_gram(N.ptr(gram), N.ptr(gram_t), s_pad, B, s_eff, code, st), "glr_tile_gram")
     tp = torch.empty(plan.n_slots, D, dtype=odt, device=dev)
     tnorm = torch.empty(plan.n_slots, dtype=torch.float32, device=dev)
     N.check(L.glr_pack_words(N.ptr(words), in_code, N.ptr(plan.sent_slot0), N.ptr(plan.cap_lens), N.ptr(tp),
                              N.ptr(tnorm), words.shape[0], D, words.shape[2], o.word_start, plan.n_slots,
                              plan.capacity, code, st), "glr_pack_words")
-    # K1 streams the K-tiled copies (contiguous 1-KiB DMA pieces); the row-major vt / tp stay for the gradient GEMMs
-    esz = vt.element_size()
-    vt_t, gram_t, tp_t = torch.empty_like(vt), torch.empty_like(gram), torch.empty_like(tp)
-    N.check(L.glr_tile_k(N.ptr(vt), N.ptr(vt_t), s_pad, B, D * esz, st), "glr_tile_k")
-    N.check(L.glr_tile_k(N.ptr(gram), N.ptr(gram_t), s_pad, B, s_pad * esz, st), "glr_tile_k")
-    N.check(L.glr_tile_k(N.ptr(tp), N.ptr(tp_t), N.TILE_WORDS, plan.n_tiles, D * esz, st), "glr_tile_k")
+    tp_t = torch.empty_like(tp)
+    N.check(L.glr_tile_k(N.ptr(tp), N.ptr(tp_t), N.TILE_WORDS, plan.n_tiles, D * vt.element_size(), st), "glr_tile_k")
     return plan, code, vt, vt_t, gram_t, tp, tp_t, tnorm, s_eff, s_pad, shift
 
 

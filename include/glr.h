@@ -124,6 +124,11 @@ int glr_plan_rowflags(const int32_t* cap_lens, const int32_t* sent_slot0, const 
 int glr_pack_regions(const void* img_features, int in_dtype, int in_layout, const void* no_attn_vec, void* vt,
                      int B, int D, int S, int op_dtype, void* stream);
 
+/* glr_pack_regions_tiled: the same packing that ALSO writes vt_t, the K-tiled copy the K1 streams read (layout of
+ * glr_tile_k with rows = S_pad) - for channels-last bf16 features in ONE pass over the input (16 bytes per thread). */
+int glr_pack_regions_tiled(const void* img_features, int in_dtype, int in_layout, const void* no_attn_vec, void* vt,
+                           void* vt_t, int B, int D, int S, int op_dtype, void* stream);
+
 int glr_pack_words(const void* words_emb, int in_dtype, const int32_t* sent_slot0_dev,
                    const int32_t* cap_lens_dev, void* tp, float* tnorm, int B_txt, int D, int L,
                    int word_start, int n_slots, int capacity, int op_dtype, void* stream);
@@ -199,6 +204,10 @@ int glr_local_attn_bwd(const void* vt, const void* gram, const void* tp, const f
  *   src   row-major [n_blocks * rows][row_bytes]     dst  same size, tiled     row_bytes % 64 == 0
  */
 int glr_tile_k(const void* src, void* dst, int rows, long long n_blocks, int row_bytes, void* stream);
+/* glr_tile_gram: K-tiling of the Gram matrices gram [B, S_pad, S_pad] (op_dtype) that also writes the ONES ROW the
+ * forward pair kernel expects when S_eff < S_pad (row S_pad - 1: ones in columns r < S_eff, zeros after; see
+ * tile_rowflags of glr_local_attn_fwd) - the row-major gram stays untouched. */
+int glr_tile_gram(const void* gram, void* gram_t, int S_pad, long long B, int S_eff, int op_dtype, void* stream);
 
 
 /* ------------------------------------------------------------------------------------------
