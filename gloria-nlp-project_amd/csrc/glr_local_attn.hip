@@ -86,7 +86,7 @@ struct LaParams {
   int strip;
   int pair_only, img_offset;
   int img_block;                // pair kernel: images per L2 group (block -> (image, item) mapping)
-  const unsigned* rowflags;     // [n_tiles][8] run boundaries per tile and lane half (glr_plan_rowflags), pair kernel
+  const int* pair_desc;         // [n_pair][64] sentences + row flags of every forward pair (glr_plan_pair_desc)
 #ifdef GLR_ABLATE
   int dbg;                      // diagnostic build only (libglr_ablate.so): phases to SKIP, GLR_K1_DBG bit mask
 #endif
@@ -911,8 +911,8 @@ __global__ void __launch_bounds__(NTHR) k_local_attn_pw(LaParams p) {
   int* seg_w0 = reinterpret_cast<int*>(wsegb + 2 * TW);
   int* seg_n = seg_w0 + PW_MAXSEG;
   int* seg_sent = seg_n + PW_MAXSEG;
-  int* misc = seg_sent + PW_MAXSEG;                              // [0] = sentences in the pair, [1..2] diagonal w0, n
-  float* tnl = reinterpret_cast<float*>(misc + 16);              // [2 * TW] word norms
+  int* misc = seg_sent + PW_MAXSEG;                              // [1..2] diagonal w0, n; [8..9] long-pair partials; [16..79] descriptor
+  float* tnl = reinterpret_cast<float*>(misc + 80);              // [2 * TW] word norms
   float* zsum = tnl + 2 * TW;                                    // [2 * TW]
   float* dsum = zsum + 2 * TW;                                   // [2 * TW]
   float* red = dsum + 2 * TW;                                    // [2 tiles][2][8][TW]
@@ -921,33 +921,25 @@ __global__ void __launch_bounds__(NTHR) k_local_attn_pw(LaParams p) {
   const unsigned char* vt_b = p.vt + (size_t)b * SP * rowbytes1;
   const unsigned char* gram_b = p.gram + (size_t)b * SP * rowbytes2;
 
+  // everything about the pair comes from ONE 256-byte descriptor (coalesced; the segment tables used to cost three
+  // dependent global round trips before the stream could start)
+  int* dsc = misc + 16;                                          // [64] LDS copy of the pair descriptor
+  if (tid < 64) dsc[tid] = p.pair_desc[(size_t)(rem / ib) * 64 + tid];
   if (tid < 2 * TW) {
     wsegb[tid] = -1;
     tnl[tid] = p.tnorm[(size_t)tile0 * TW + tid];
   }
   if (tid < 3) misc[tid] = 0;
-  const bool long_pair = p.tile_nsub[tile0] == 2;
-  {
-    const int sf0 = p.tile_first[tile0], sf2 = p.tile_first[tile0 + 2];
-    const int ns = long_pair ? 1 : sf2 - sf0;
-    if (ns > PW_MAXSEG) {                        // planner contract violated (glr_plan_items max_pair_seg <= 8): fail loudly
-      if (tid < ns) p.sim[(size_t)b * p.ld_sim + p.order[sf0 + tid]] = __builtin_nanf("");
-      return;
-    }
-    if (tid == 0) misc[0] = ns;
-    if (tid < ns) {
-      const int sent = p.order[sf0 + tid];
-      seg_sent[tid] = sent;
-      seg_w0[tid] = p.sent_slot0[sent] - tile0 * TW;
-      seg_n[tid] = p.cap_lens[sent];
-    }
-  }
   __syncthreads();
-  const int NS = misc[0];
+  const int NS = dsc[0];
+  const bool long_pair = dsc[1] != 0;
   if (tid < NS) {
-    const int w0 = seg_w0[tid], n = seg_n[tid];
+    const int sent = dsc[8 + tid], w0 = dsc[16 + tid], n = dsc[24 + tid];
+    seg_sent[tid] = sent;
+    seg_w0[tid] = w0;
+    seg_n[tid] = n;
     for (int w = 0; w < n; ++w) wsegb[w0 + w] = (signed char)tid;
-    if (seg_sent[tid] == p.img_offset + b) { misc[1] = w0; misc[2] = n; }
+    if (sent == p.img_offset + b) { misc[1] = w0; misc[2] = n; }
   }
   // ================= P1 (both tiles, one stream of vt[b]) =================
   f32x16 acc0[3], acc1[3];
@@ -962,10 +954,11 @@ __global__ void __launch_bounds__(NTHR) k_local_attn_pw(LaParams p) {
                            rowbytes1, vt_b, rowbytes1, SP, (int)(rowbytes1 / CB), nullptr, 0, wave, lane, 0, wg, NRB, TW);
   GLR_STAMP2(2);
 
-  // run boundaries of this wave's tile (scalar: same for every lane of a half); loaded after the stream so that
-  // they are not carried (and spilled) through it
-  const unsigned* fl = p.rowflags + (size_t)(tile0 + t) * 8;
-  const unsigned ST0 = fl[0], ST1 = fl[1], LA0 = fl[2], LA1 = fl[3];
+  // run boundaries of this wave's tile (scalar: same for every lane of a half); read from the LDS copy of the
+  // descriptor after the stream so that they are not carried (and spilled) through it
+  const int* fl = dsc + 32 + 8 * t;
+  const unsigned ST0 = __builtin_amdgcn_readfirstlane(fl[0]), ST1 = __builtin_amdgcn_readfirstlane(fl[1]),
+                 LA0 = __builtin_amdgcn_readfirstlane(fl[2]), LA1 = __builtin_amdgcn_readfirstlane(fl[3]);
   const unsigned STANY = ST0 | ST1, LAANY = LA0 | LA1;
   const unsigned STh = h ? ST1 : ST0, LAh = h ? LA1 : LA0;
   // a wave-uniform bit test the compiler must keep as a SCALAR branch: without the opaque copy it folds the test
@@ -1348,7 +1341,7 @@ int launch_pair(LaParams& p, int op_dtype, void* stream) {
   const int per_xcd = ((p.B_img + 7) / 8 + p.img_block - 1) / p.img_block * p.img_block;
   const int grid = per_xcd * 8 * p.n_items;
   // the pair kernel needs the planner's row flags and a spare padded region for the ones row of the Gram operand
-  if (p.rowflags == nullptr || p.S_eff >= p.S_pad) return GLR_EINVAL;
+  if (p.pair_desc == nullptr || p.S_eff >= p.S_pad) return GLR_EINVAL;
 #ifdef GLR_ABLATE
   { const char* e = getenv("GLR_K1_DBG"); p.dbg = e ? atoi(e) : 0; }
 #endif
@@ -1370,7 +1363,7 @@ int fill_common(LaParams& p, const void* vt, const void* gram, const void* tp, c
   if (agg < 0 || agg > 2) return GLR_EINVAL;
   p.vt = (const unsigned char*)vt; p.gram = (const unsigned char*)gram; p.tp = (const unsigned char*)tp;
   p.tnorm = tnorm; p.sent_slot0 = sent_slot0; p.cap_lens = cap_lens; p.tile_first = tile_first; p.order = order;
-  p.tile_nsub = tile_nsub; p.item_tile = nullptr; p.n_items = 0; p.amean = nullptr; p.damean = nullptr; p.dattn = nullptr; p.rowflags = nullptr; p.n_tiles = n_tiles; p.n_sent = n_sent;
+  p.tile_nsub = tile_nsub; p.item_tile = nullptr; p.n_items = 0; p.amean = nullptr; p.damean = nullptr; p.dattn = nullptr; p.pair_desc = nullptr; p.n_tiles = n_tiles; p.n_sent = n_sent;
   p.n_slots = n_tiles * TW; p.B_img = B_img;
   p.D = D; p.S_eff = S_eff; p.S_pad = S_pad; p.temp1 = temp1; p.temp2 = temp2; p.temp3 = temp3; p.agg = agg;
   p.eps = eps;
@@ -1391,7 +1384,7 @@ extern "C" int glr_local_attn_fwd(const void* vt, const void* gram, const void* 
                                   const int32_t* sent_slot0, const int32_t* cap_lens,
                                   const int32_t* tile_first, const int32_t* order, const int32_t* tile_nsub,
                                   const int32_t* single_tile, int n_single, const int32_t* pair_tile, int n_pair,
-                                  const uint32_t* tile_rowflags,
+                                  const int32_t* pair_desc,
                                   int n_tiles, int n_sent, int B_img, int D, int S_eff, float temp1, float temp2,
                                   float temp3, int agg, float eps, float* sim, int ld_sim, float* lse, float* wstat,
                                   float* attn, const int64_t* attn_off, int strip, int pair_only, int img_offset,
@@ -1413,7 +1406,7 @@ extern "C" int glr_local_attn_fwd(const void* vt, const void* gram, const void* 
     if (rc != GLR_OK) return rc;
   }
   if (!pair_only && n_pair > 0) {
-    p.item_tile = pair_tile; p.n_items = n_pair; p.rowflags = tile_rowflags;
+    p.item_tile = pair_tile; p.n_items = n_pair; p.pair_desc = pair_desc;
     rc = launch_pair(p, op_dtype, stream);
   }
   return rc;

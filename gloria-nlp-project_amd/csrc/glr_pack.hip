@@ -165,6 +165,43 @@ extern "C" int glr_plan_rowflags(const int32_t* cap_lens, const int32_t* sent_sl
   return GLR_OK;
 }
 
+// Pair descriptors of the forward pair kernel: everything a workgroup needs to know about its pair of tiles in ONE
+// coalesced 256-byte read (instead of three dependent global round trips through tile_first / order / sent_slot0 /
+// cap_lens plus the row flags):  desc[pair][64] int32 =
+//   [0] sentences in the pair (<= 8), [1] 1 = ONE sentence of 65..128 words owning both tiles, [2..7] 0
+//   [8..15] sentence ids, [16..23] first slot in the pair (0..127), [24..31] words, [32..39] / [40..47] row flags of
+//   tile A / B (glr_plan_rowflags layout), [48..63] 0
+extern "C" int glr_plan_pair_desc(const int32_t* cap_lens, const int32_t* sent_slot0, const int32_t* tile_first,
+                                  const int32_t* order, const int32_t* tile_nsub, int n_tiles, int capacity,
+                                  const int32_t* pair_tile, int n_pair, int32_t* desc) {
+  if (!pair_tile || !desc || n_pair <= 0) return GLR_EINVAL;
+  std::vector<uint32_t> flags(8 * (size_t)n_tiles);
+  const int rc = glr_plan_rowflags(cap_lens, sent_slot0, tile_first, order, tile_nsub, n_tiles, capacity, flags.data());
+  if (rc != GLR_OK) return rc;
+  memset(desc, 0, sizeof(int32_t) * 64 * (size_t)n_pair);
+  for (int k = 0; k < n_pair; ++k) {
+    const int t0 = pair_tile[k];
+    if (t0 < 0 || t0 + 1 >= n_tiles) return GLR_EINVAL;
+    int32_t* d = desc + 64 * (size_t)k;
+    const bool lp = tile_nsub[t0] == 2;
+    const int ns = lp ? 1 : tile_first[t0 + 2] - tile_first[t0];
+    if (ns < 1 || ns > 8) return GLR_EINVAL;
+    d[0] = ns;
+    d[1] = lp ? 1 : 0;
+    for (int s = 0; s < ns; ++s) {
+      const int sent = order[tile_first[t0] + s];
+      d[8 + s] = sent;
+      d[16 + s] = sent_slot0[sent] - t0 * GLR_TILE_WORDS;
+      d[24 + s] = cap_lens[sent];
+    }
+    for (int q = 0; q < 8; ++q) {
+      d[32 + q] = (int32_t)flags[8 * (size_t)t0 + q];
+      d[40 + q] = (int32_t)flags[8 * (size_t)(t0 + 1) + q];
+    }
+  }
+  return GLR_OK;
+}
+
 namespace {
 
 // grid (S_pad/64, D/64, B), 256 threads: one 64(feature) x 64(region) tile.

@@ -28,6 +28,7 @@ SYMBOLS = {
     "glr_plan_tiles": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "glr_plan_items": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "glr_plan_rowflags": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "glr_plan_pair_desc": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p]),
     "glr_tile_k": (c_int, [c_void_p, c_void_p, c_int, ctypes.c_longlong, c_int, c_void_p]),
     "glr_pack_regions": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "glr_pack_regions_tiled": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
@@ -166,13 +167,22 @@ class TilePlan:
             if rc != 0:
                 raise ValueError(f"glr_plan_rowflags failed ({rc})")
         self.rowflags_host = flags.reshape(nt, 8)
+        # one 256-byte descriptor per forward pair (sentences + row flags): what a workgroup reads about its pair
+        desc = np.zeros(max(self.n_pair, 1) * 64, dtype=np.int32)
+        if self.n_pair:
+            rc = L.glr_plan_pair_desc(cl.ctypes.data_as(c_void_p), slot0.ctypes.data_as(c_void_p),
+                                      tile_first.ctypes.data_as(c_void_p), order.ctypes.data_as(c_void_p),
+                                      nsub.ctypes.data_as(c_void_p), nt, capacity, pairs.ctypes.data_as(c_void_p),
+                                      self.n_pair, desc.ctypes.data_as(c_void_p))
+            if rc != 0:
+                raise ValueError(f"glr_plan_pair_desc failed ({rc})")
         self.capacity = capacity
         self.cap_lens_host = cl
         self.n_sent, self.n_tiles, self.n_slots = n, nt, nt * TILE_WORDS
         self.sent_slot0_host = slot0
         self.n_words = int(cl.sum())
         pack = np.concatenate([cl, slot0, tile_first[: nt + 1], order, nsub[:nt], singles[:self.n_single],
-                               pairs[:self.n_pair], alls[:self.n_all], flags.view(np.int32)]).astype(np.int32)
+                               pairs[:self.n_pair], alls[:self.n_all], desc[:self.n_pair * 64]]).astype(np.int32)
         dev = torch.from_numpy(pack).to(device, non_blocking=True)
         o = 0
         self.cap_lens = dev[o:o + n]; o += n
@@ -183,7 +193,7 @@ class TilePlan:
         self.single_tile = dev[o:o + self.n_single]; o += self.n_single
         self.pair_tile = dev[o:o + self.n_pair]; o += self.n_pair
         self.all_tile = dev[o:o + self.n_all]; o += self.n_all
-        self.rowflags = dev[o:o + nt * 8] if self.n_pair else None
+        self.pair_desc = dev[o:o + self.n_pair * 64] if self.n_pair else None
         self._dev = dev
         self._word_index = None
 

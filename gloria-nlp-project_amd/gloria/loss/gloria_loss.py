@@ -141,7 +141,7 @@ def _k1_args(plan, vt, gram, tp, tnorm, B, D, s_eff, o, backward=False):
         items = (N.ptr(plan.all_tile), plan.n_all)
     else:
         items = (N.ptr(plan.single_tile) if plan.n_single else None, plan.n_single,
-                 N.ptr(plan.pair_tile) if plan.n_pair else None, plan.n_pair, N.ptr(plan.rowflags))
+                 N.ptr(plan.pair_tile) if plan.n_pair else None, plan.n_pair, N.ptr(plan.pair_desc))
     return head + items + (plan.n_tiles, plan.n_sent, B, D, s_eff, o.temp1, o.temp2, o.temp3, N.AGG[o.agg], o.eps)
 
 

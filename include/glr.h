@@ -102,6 +102,14 @@ int glr_plan_items(const int32_t* tile_nsub, const int32_t* tile_first, int n_ti
 int glr_plan_rowflags(const int32_t* cap_lens, const int32_t* sent_slot0, const int32_t* tile_first,
                       const int32_t* order, const int32_t* tile_nsub, int n_tiles, int capacity, uint32_t* flags);
 
+/* Pair descriptors (host): per forward pair ONE 256-byte record with its sentences (ids, first slots, lengths) and the
+ * row flags of both tiles - what a workgroup of the pair kernel reads (coalesced, once) instead of walking tile_first /
+ * order / sent_slot0 / cap_lens.  desc[n_pair][64] int32: [0] sentences (<= 8), [1] long-pair flag, [8..15] sentence
+ * ids, [16..23] first slot in the pair, [24..31] words, [32..39] / [40..47] glr_plan_rowflags of tile A / B. */
+int glr_plan_pair_desc(const int32_t* cap_lens, const int32_t* sent_slot0, const int32_t* tile_first,
+                       const int32_t* order, const int32_t* tile_nsub, int n_tiles, int capacity,
+                       const int32_t* pair_tile, int n_pair, int32_t* desc);
+
 /* ------------------------------------------------------------------------------------------
  * Operand packing (device).  HBM-bound layout/convert kernels.
  *
@@ -149,11 +157,11 @@ int glr_pack_words(const void* words_emb, int in_dtype, const int32_t* sent_slot
  *   tile_first, order, tile_nsub   device int32 copies of the glr_plan_tiles outputs
  *   single_tile/n_single, pair_tile/n_pair (fwd), item_tile/n_items (bwd: the all_tile list)
  *                device int32 copies of the glr_plan_items outputs
- *   tile_rowflags  (fwd) device copy of the glr_plan_rowflags output [n_tiles][8], or NULL.  With it, and with
- *                S_eff < S_pad, pairs run the wave-owned-words kernel, which also expects gram[b] to carry ONES in
- *                row S_pad - 1, columns r < S_eff (a padded region): the second contraction then delivers
- *                Z_w = sum_r e2[w, r] in output column S_pad - 1.  Every other kernel masks padded regions, so
- *                the same gram serves them and the backward.
+ *   pair_desc    (fwd) device copy of the glr_plan_pair_desc output [n_pair][64]; required when n_pair > 0.  The
+ *                pair kernel also needs S_eff < S_pad and expects gram[b] to carry ONES in row S_pad - 1, columns
+ *                r < S_eff (a padded region; glr_tile_gram writes it): the second contraction then delivers
+ *                Z_w = sum_r e2[w, r] in output column S_pad - 1.  Every other kernel masks padded regions, so the
+ *                same gram serves them and the backward.
  *   sim          fp32 [B_img, ld_sim]; column = sentence id (fwd: out, bwd: in)
  *   lse          fp32 [B_img, n_sent, S_pad]: log-sum-exp over the words of sentence i of the
  *                scores of region r (fwd: optional out, needed by bwd)
@@ -183,7 +191,7 @@ int glr_pack_words(const void* words_emb, int in_dtype, const int32_t* sent_slot
 int glr_local_attn_fwd(const void* vt, const void* gram, const void* tp, const float* tnorm,
                        const int32_t* sent_slot0, const int32_t* cap_lens, const int32_t* tile_first,
                        const int32_t* order, const int32_t* tile_nsub, const int32_t* single_tile, int n_single,
-                       const int32_t* pair_tile, int n_pair, const uint32_t* tile_rowflags, int n_tiles, int n_sent,
+                       const int32_t* pair_tile, int n_pair, const int32_t* pair_desc, int n_tiles, int n_sent,
                        int B_img, int D, int S_eff, float temp1, float temp2, float temp3, int agg, float eps,
                        float* sim, int ld_sim, float* lse, float* wstat, float* attn, const int64_t* attn_off,
                        int strip, int pair_only, int img_offset, float* amean, int op_dtype, void* stream);
