@@ -1,0 +1,336 @@
+// Fused training-mode BatchNorm2d + (residual add) + ReLU for channels-last bf16 activations: the 53 normalisation
+// sites of the ResNet-50 image encoder (reference: torchvision resnet50 driven by
+// /root/reference/gloria/models/cnn_backbones.py:31-35 and vision_model.py:67-86; Bottleneck = conv-bn-relu x2,
+// conv-bn, + identity, relu).
+//
+// HBM-bound.  torch runs a site as BatchNorm (mean/variance pass + normalise pass; backward: scale/bias-gradient pass
+// + dx pass) plus separate add / relu / relu-backward kernels: 13 tensor passes per site and direction pair without a
+// skip connection, 19 with one.  Fused, an activation tensor of E bytes moves
+//   forward   stats : read x                          E        apply: read x (+ skip), write y          2E (3E)
+//   backward  reduce: read x, dy (+ y, write dz)      2E (4E)  apply: read x, dy (dz), write dx         3E
+// (the ReLU mask is recomputed from x; with a skip connection it comes from y, and the masked gradient dz - which
+// IS the skip connection's gradient - is written by the reduce pass and re-read by the apply pass).
+//
+// x is viewed [R = N*H*W, C], C contiguous; a thread owns 8 consecutive channels (one 16-byte load per row).
+// * reduce passes: a workgroup owns a contiguous slab of rows (sequential DRAM pages), 8 (4) independent 16-byte
+//   loads per thread in flight, ~2048 workgroups: ~128 KB in flight per CU, which is what ~6 TB/s needs at HBM
+//   latency.  Per-workgroup partial sums [n_part][2][C] are combined in a fixed order by a small second kernel:
+//   bitwise reproducible.
+// * apply passes: short workgroups (256 threads x 4 vectors), and they walk the tensor in the OPPOSITE direction of the
+//   reduce pass in front of them, so the tail the reduce pass touched last is still in the 256 MB Infinity Cache.
+#include "glr_common.h"
+
+namespace {
+
+constexpr int BN_NT = 256;
+constexpr int BN_WG_TARGET = 2048;        // workgroups of a reduce pass
+constexpr int BN_FIN_NT = 1024;
+
+__device__ __forceinline__ void unpack8(const uint4 u, float (&f)[8]) {
+  const unsigned w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    f[2 * i] = __uint_as_float(w[i] << 16);
+    f[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+  }
+}
+__device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
+  unsigned w[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) w[i] = (unsigned)f2bf(f[2 * i]) | ((unsigned)f2bf(f[2 * i + 1]) << 16);
+  return make_uint4(w[0], w[1], w[2], w[3]);
+}
+__device__ __forceinline__ uint4 ldv(const unsigned short* p) { return *reinterpret_cast<const uint4*>(p); }
+__device__ __forceinline__ void stv(unsigned short* p, uint4 v) { *reinterpret_cast<uint4*>(p) = v; }
+
+// ---- pass 1 of both directions: per-channel partial sums of two quantities over a slab of rows
+//   MODE 0 (forward stats)  q0 = x,  q1 = x^2
+//   MODE 1 (backward)       q0 = dz, q1 = dz * xhat,  dz = dy * [z > 0]   (RESID: mask from y, dz also written out)
+template <int MODE, bool RESID>
+__global__ void __launch_bounds__(BN_NT) k_bn_reduce(const unsigned short* __restrict__ x, const unsigned short* __restrict__ dy,
+                                                     const unsigned short* __restrict__ y, const float* __restrict__ mean,
+                                                     const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, long long R, int C, int relu,
+                                                     long long rows_per_part, float* __restrict__ part,
+                                                     unsigned short* __restrict__ dz_out) {
+  constexpr int UN = MODE == 0 ? 8 : 4;
+  const int cg_per_blk = min(C / 8, 32), rl_per_blk = BN_NT / cg_per_blk;
+  const int cg = blockIdx.x * cg_per_blk + threadIdx.x % cg_per_blk, rl = threadIdx.x / cg_per_blk;
+  const int c0 = cg * 8;
+  float a0[8], a1[8], mu[8], is[8], sc[8], sh[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    a0[i] = a1[i] = 0.f;
+    if (MODE == 1) {
+      mu[i] = mean[c0 + i]; is[i] = invstd[c0 + i];
+      sc[i] = is[i] * gamma[c0 + i];
+      sh[i] = beta[c0 + i] - mu[i] * sc[i];          // z = fma(x, sc, sh): the forward's own expression (same mask)
+    }
+  }
+  const long long r_begin = (long long)blockIdx.y * rows_per_part;
+  const long long r_end = min(R, r_begin + rows_per_part);
+  for (long long r = r_begin + rl; r < r_end; r += (long long)UN * rl_per_blk) {
+    uint4 xr[UN], dr[UN], yr[UN];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const long long ru = r + (long long)u * rl_per_blk;
+      if (ru < r_end) {
+        xr[u] = ldv(x + ru * C + c0);
+        if (MODE == 1) dr[u] = ldv(dy + ru * C + c0);
+        if (MODE == 1 && RESID) yr[u] = ldv(y + ru * C + c0);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const long long ru = r + (long long)u * rl_per_blk;
+      if (ru < r_end) {
+        float xv[8];
+        unpack8(xr[u], xv);
+        if (MODE == 0) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) { a0[i] += xv[i]; a1[i] = __builtin_fmaf(xv[i], xv[i], a1[i]); }
+        } else {
+          float dv[8], yv[8], dzv[8];
+          unpack8(dr[u], dv);
+          if (RESID) unpack8(yr[u], yv);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const bool on = !relu || (RESID ? yv[i] > 0.f : __builtin_fmaf(xv[i], sc[i], sh[i]) > 0.f);
+            const float dz = on ? dv[i] : 0.f;
+            dzv[i] = dz;
+            a0[i] += dz;
+            a1[i] = __builtin_fmaf(dz, (xv[i] - mu[i]) * is[i], a1[i]);
+          }
+          if (RESID) stv(dz_out + ru * C + c0, pack8(dzv));
+        }
+      }
+    }
+  }
+  // reduce over the row lanes of the block (fixed order), one partial per (blockIdx.y, channel)
+  __shared__ float red[2][BN_NT][8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { red[0][threadIdx.x][i] = a0[i]; red[1][threadIdx.x][i] = a1[i]; }
+  __syncthreads();
+  // thread t < 8 cg_per_blk sums channel column t of both quantities over the row lanes
+  const int ncol = cg_per_blk * 8;
+  if ((int)threadIdx.x < ncol) {
+    const int col = threadIdx.x, tcg = col >> 3, ti = col & 7;
+    float s0 = 0.f, s1 = 0.f;
+    for (int k = 0; k < rl_per_blk; ++k) { s0 += red[0][k * cg_per_blk + tcg][ti]; s1 += red[1][k * cg_per_blk + tcg][ti]; }
+    part[((size_t)blockIdx.y * 2 + 0) * C + (size_t)blockIdx.x * ncol + col] = s0;
+    part[((size_t)blockIdx.y * 2 + 1) * C + (size_t)blockIdx.x * ncol + col] = s1;
+  }
+}
+
+// second stage: fixed-order sums of the partials in double, 32 channels x 32 part lanes per workgroup
+//   FWD: mean / invstd (+ running statistics, momentum form of nn.BatchNorm2d)
+//   BWD: dgamma, dbeta and the two per-channel means the dx formula needs
+template <bool FWD>
+__global__ void __launch_bounds__(BN_FIN_NT) k_bn_finish(const float* __restrict__ part, int n_part, int C, long long R, float eps,
+                                                         float momentum, float* __restrict__ o0, float* __restrict__ o1,
+                                                         float* __restrict__ o2, float* __restrict__ o3) {
+  __shared__ double red[2][32][33];
+  const int cl = threadIdx.x & 31, pl = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
+  double s = 0.0, ss = 0.0;
+  if (c < C)
+    for (int k = pl; k < n_part; k += 32) { s += (double)part[((size_t)k * 2) * C + c]; ss += (double)part[((size_t)k * 2 + 1) * C + c]; }
+  red[0][pl][cl] = s;
+  red[1][pl][cl] = ss;
+  __syncthreads();
+  if (pl != 0 || c >= C) return;
+  s = 0.0; ss = 0.0;
+  for (int k = 0; k < 32; ++k) { s += red[0][k][cl]; ss += red[1][k][cl]; }
+  if (FWD) {
+    const double m = s / (double)R;
+    double var = ss / (double)R - m * m;
+    if (var < 0.0) var = 0.0;
+    o0[c] = (float)m;                                        // mean
+    o1[c] = (float)(1.0 / sqrt(var + (double)eps));          // invstd
+    if (o2) {                                                // running mean / var
+      const double unb = R > 1 ? var * (double)R / (double)(R - 1) : var;
+      o2[c] = (1.f - momentum) * o2[c] + momentum * (float)m;
+      o3[c] = (1.f - momentum) * o3[c] + momentum * (float)unb;
+    }
+  } else {
+    o0[c] = (float)ss;                                       // dgamma
+    o1[c] = (float)s;                                        // dbeta
+    o2[c] = (float)(s / (double)R);                          // mean(dz)
+    o3[c] = (float)(ss / (double)R);                         // mean(dz xhat)
+  }
+}
+
+// forward apply: y = relu?( (x - mean) invstd gamma + beta (+ residual) ); blocks walk the tensor backwards
+template <bool RESID>
+__global__ void __launch_bounds__(BN_NT) k_bn_apply(const unsigned short* __restrict__ x, const unsigned short* __restrict__ res,
+                                                    const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                    const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                    long long n_vec, int C, int relu, unsigned short* __restrict__ y) {
+  constexpr int UN = 4;
+  const unsigned cpr = (unsigned)C / 8u;                     // a power of two <= 256: a thread keeps its channels
+  const int c0 = (int)(threadIdx.x & (cpr - 1)) * 8;
+  const long long v0 = (long long)(gridDim.x - 1 - blockIdx.x) * (BN_NT * UN) + threadIdx.x;
+  uint4 xr[UN], rr[UN];
+#pragma unroll
+  for (int u = 0; u < UN; ++u) {
+    const long long v = v0 + u * BN_NT;
+    if (v < n_vec) {
+      xr[u] = ldv(x + v * 8);
+      if (RESID) rr[u] = ldv(res + v * 8);
+    }
+  }
+  float sc[8], sh[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    sc[i] = invstd[c0 + i] * gamma[c0 + i];
+    sh[i] = beta[c0 + i] - mean[c0 + i] * sc[i];
+  }
+#pragma unroll
+  for (int u = 0; u < UN; ++u) {
+    const long long v = v0 + u * BN_NT;
+    if (v < n_vec) {
+      float xv[8], rv[8], o[8];
+      unpack8(xr[u], xv);
+      if (RESID) unpack8(rr[u], rv);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        float z = __builtin_fmaf(xv[i], sc[i], sh[i]);
+        if (RESID) z += rv[i];
+        o[i] = relu ? fmaxf(z, 0.f) : z;
+      }
+      stv(y + v * 8, pack8(o));
+    }
+  }
+}
+
+// backward apply: dx = (dz - mean(dz) - xhat mean(dz xhat)) invstd gamma.  RESID: `dy` is the dz the reduce pass wrote.
+template <bool RESID>
+__global__ void __launch_bounds__(BN_NT) k_bn_bwd_apply(const unsigned short* __restrict__ x, const unsigned short* __restrict__ dy,
+                                                        const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        const float* __restrict__ m_dz, const float* __restrict__ m_dzx,
+                                                        long long n_vec, int C, int relu, unsigned short* __restrict__ dx) {
+  constexpr int UN = 4;
+  const unsigned cpr = (unsigned)C / 8u;
+  const int c0 = (int)(threadIdx.x & (cpr - 1)) * 8;
+  const long long v0 = (long long)(gridDim.x - 1 - blockIdx.x) * (BN_NT * UN) + threadIdx.x;
+  uint4 xr[UN], dr[UN];
+#pragma unroll
+  for (int u = 0; u < UN; ++u) {
+    const long long v = v0 + u * BN_NT;
+    if (v < n_vec) {
+      xr[u] = ldv(x + v * 8);
+      dr[u] = ldv(dy + v * 8);
+    }
+  }
+  // dx = dz * k1 - (k2 + x * k3):  k1 = invstd gamma, k3 = invstd mean(dz xhat) k1, k2 = mean(dz) k1 - mean k3
+  float k1[8], k2[8], k3[8], sh[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const float is = invstd[c0 + i], mu = mean[c0 + i];
+    k1[i] = is * gamma[c0 + i];
+    k3[i] = is * m_dzx[c0 + i] * k1[i];
+    k2[i] = m_dz[c0 + i] * k1[i] - mu * k3[i];
+    sh[i] = beta[c0 + i] - mu * k1[i];
+  }
+#pragma unroll
+  for (int u = 0; u < UN; ++u) {
+    const long long v = v0 + u * BN_NT;
+    if (v < n_vec) {
+      float xv[8], dv[8], o[8];
+      unpack8(xr[u], xv);
+      unpack8(dr[u], dv);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const bool on = RESID || !relu || __builtin_fmaf(xv[i], k1[i], sh[i]) > 0.f;
+        const float dz = on ? dv[i] : 0.f;
+        o[i] = __builtin_fmaf(dz, k1[i], -__builtin_fmaf(xv[i], k3[i], k2[i]));
+      }
+      stv(dx + v * 8, pack8(o));
+    }
+  }
+}
+
+struct BnPlan { int cg_per_blk, col_blocks, n_part; long long rows_per_part; };
+
+BnPlan bn_plan(long long R, int C) {
+  BnPlan p;
+  p.cg_per_blk = C / 8 < 32 ? C / 8 : 32;
+  p.col_blocks = (C / 8) / p.cg_per_blk;
+  const int rl = BN_NT / p.cg_per_blk;
+  long long want = BN_WG_TARGET / p.col_blocks;
+  const long long min_rows = (long long)rl * 8;              // at least one full unrolled step per workgroup
+  long long rpp = (R + want - 1) / want;
+  if (rpp < min_rows) rpp = min_rows;
+  rpp = (rpp + rl - 1) / rl * rl;
+  p.rows_per_part = rpp;
+  p.n_part = (int)((R + rpp - 1) / rpp);
+  return p;
+}
+
+bool bn_shape_ok(long long R, int C) { return R > 0 && C >= 8 && C <= 2048 && (C & (C - 1)) == 0; }
+
+}  // namespace
+
+extern "C" int glr_bn_workspace_floats(long long R, int C) {
+  if (!bn_shape_ok(R, C)) return 0;
+  return bn_plan(R, C).n_part * 2 * C;
+}
+
+extern "C" int glr_bn_act_fwd(const void* x, const void* residual, const float* gamma, const float* beta, long long R,
+                              int C, float eps, float momentum, int relu, float* run_mean, float* run_var, float* mean,
+                              float* invstd, float* workspace, void* y, void* stream) {
+  if (!x || !gamma || !beta || !mean || !invstd || !workspace || !y || !bn_shape_ok(R, C)) return GLR_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const BnPlan pl = bn_plan(R, C);
+  hipLaunchKernelGGL((k_bn_reduce<0, false>), dim3(pl.col_blocks, pl.n_part), dim3(BN_NT), 0, st, (const unsigned short*)x,
+                     nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, R, C, 0, pl.rows_per_part, workspace, nullptr);
+  GLR_CHECK_LAUNCH();
+  hipLaunchKernelGGL((k_bn_finish<true>), dim3((C + 31) / 32), dim3(BN_FIN_NT), 0, st, workspace, pl.n_part, C, R, eps, momentum,
+                     mean, invstd, run_mean, run_var);
+  GLR_CHECK_LAUNCH();
+  const long long n_vec = R * C / 8;
+  const int grid = (int)((n_vec + BN_NT * 4 - 1) / (BN_NT * 4));
+  if (residual)
+    hipLaunchKernelGGL((k_bn_apply<true>), dim3(grid), dim3(BN_NT), 0, st, (const unsigned short*)x, (const unsigned short*)residual,
+                       mean, invstd, gamma, beta, n_vec, C, relu, (unsigned short*)y);
+  else
+    hipLaunchKernelGGL((k_bn_apply<false>), dim3(grid), dim3(BN_NT), 0, st, (const unsigned short*)x, nullptr, mean, invstd, gamma,
+                       beta, n_vec, C, relu, (unsigned short*)y);
+  GLR_CHECK_LAUNCH();
+  return GLR_OK;
+}
+
+// out4c = [dgamma | dbeta | mean(dz) | mean(dz xhat)], 4*C floats.  has_residual: `y` (the forward's output) gives
+// the ReLU mask and `dres` receives the masked gradient (the skip connection's gradient).
+extern "C" int glr_bn_act_bwd(const void* x, const void* dy, const void* y, const float* gamma, const float* beta,
+                              const float* mean, const float* invstd, long long R, int C, int relu, int has_residual,
+                              float* workspace, float* out4c, void* dx, void* dres, void* stream) {
+  if (!x || !dy || !gamma || !beta || !mean || !invstd || !workspace || !out4c || !dx || !bn_shape_ok(R, C) ||
+      (has_residual && (!y || !dres)))
+    return GLR_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const BnPlan pl = bn_plan(R, C);
+  const dim3 rgrid(pl.col_blocks, pl.n_part);
+  if (has_residual)
+    hipLaunchKernelGGL((k_bn_reduce<1, true>), rgrid, dim3(BN_NT), 0, st, (const unsigned short*)x, (const unsigned short*)dy,
+                       (const unsigned short*)y, mean, invstd, gamma, beta, R, C, relu, pl.rows_per_part, workspace,
+                       (unsigned short*)dres);
+  else
+    hipLaunchKernelGGL((k_bn_reduce<1, false>), rgrid, dim3(BN_NT), 0, st, (const unsigned short*)x, (const unsigned short*)dy,
+                       nullptr, mean, invstd, gamma, beta, R, C, relu, pl.rows_per_part, workspace, nullptr);
+  GLR_CHECK_LAUNCH();
+  hipLaunchKernelGGL((k_bn_finish<false>), dim3((C + 31) / 32), dim3(BN_FIN_NT), 0, st, workspace, pl.n_part, C, R, 0.f, 0.f, out4c,
+                     out4c + C, out4c + 2 * C, out4c + 3 * C);
+  GLR_CHECK_LAUNCH();
+  const long long n_vec = R * C / 8;
+  const int grid = (int)((n_vec + BN_NT * 4 - 1) / (BN_NT * 4));
+  if (has_residual)
+    hipLaunchKernelGGL((k_bn_bwd_apply<true>), dim3(grid), dim3(BN_NT), 0, st, (const unsigned short*)x, (const unsigned short*)dres,
+                       mean, invstd, gamma, beta, out4c + 2 * C, out4c + 3 * C, n_vec, C, relu, (unsigned short*)dx);
+  else
+    hipLaunchKernelGGL((k_bn_bwd_apply<false>), dim3(grid), dim3(BN_NT), 0, st, (const unsigned short*)x, (const unsigned short*)dy,
+                       mean, invstd, gamma, beta, out4c + 2 * C, out4c + 3 * C, n_vec, C, relu, (unsigned short*)dx);
+  GLR_CHECK_LAUNCH();
+  return GLR_OK;
+}

@@ -53,6 +53,11 @@ SYMBOLS = {
     "glr_clip_coef": (c_int, [c_void_p, c_int, c_float, c_void_p, c_void_p]),
     "glr_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, ctypes.c_longlong, c_float,
                               c_float, c_float, c_float, c_float, c_int, c_void_p, c_void_p]),
+    "glr_bn_workspace_floats": (c_int, [ctypes.c_longlong, c_int]),
+    "glr_bn_act_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_longlong, c_int, c_float, c_float, c_int,
+                               c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "glr_bn_act_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_longlong,
+                               c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "glr_cell_counts": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "glr_kth_value": (c_int, [c_void_p, c_int, ctypes.c_longlong, ctypes.c_longlong, c_void_p, c_void_p]),
     "glr_topk_desc": (c_int, [c_void_p, c_int, ctypes.c_longlong, c_int, c_void_p, c_void_p, c_void_p]),

@@ -11,6 +11,7 @@ import warnings
 import torch
 import torch.nn as nn
 
+from .fused_bn import fused_bn_act
 
 
 class Identity(nn.Module):
@@ -33,13 +34,15 @@ class Bottleneck(nn.Module):
         self.downsample = downsample
 
     def forward(self, x):
+        # BatchNorm + ReLU (+ the skip connection) run as one fused HIP pass pair per direction on channels-last bf16
+        # (gloria/models/fused_bn.py); same modules / parameters / buffers as torchvision's bottleneck
         identity = x
-        out = self.relu(self.bn1(self.conv1(x)))
-        out = self.relu(self.bn2(self.conv2(out)))
-        out = self.bn3(self.conv3(out))
+        out = fused_bn_act(self.bn1, self.conv1(x))
+        out = fused_bn_act(self.bn2, self.conv2(out))
+        out = self.conv3(out)
         if self.downsample is not None:
-            identity = self.downsample(x)
-        return self.relu(out + identity)
+            identity = fused_bn_act(self.downsample[1], self.downsample[0](x), relu=False)
+        return fused_bn_act(self.bn3, out, residual=identity)
 
 
 class ResNet50(nn.Module):
@@ -74,7 +77,7 @@ class ResNet50(nn.Module):
         return nn.Sequential(*layers)
 
     def forward(self, x):
-        x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
+        x = self.maxpool(fused_bn_act(self.bn1, self.conv1(x)))
         x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
         return self.fc(torch.flatten(self.avgpool(x), 1))
 

@@ -1,0 +1,85 @@
+"""BatchNorm2d (+ residual add) (+ ReLU) as ONE pair of HBM passes per direction on channels-last bf16 activations
+(include/glr.h: glr_bn_act_fwd / glr_bn_act_bwd) for the 53 normalisation sites of the ResNet-50 image encoder
+(reference: torchvision's Bottleneck through /root/reference/gloria/models/cnn_backbones.py:31-35).
+
+Same parameters, buffers and state_dict keys as nn.BatchNorm2d: `fused_bn_act` is called WITH the nn.BatchNorm2d
+module.  The kernels cover what the training step runs (GPU, bf16 autocast, channels-last, training mode, power-of-two
+channel counts); every other case (fp32 parity mode, eval mode, NCHW, CPU tensors of the host-logic tests) is torch's
+own BatchNorm + add + relu - the same operator from the library, not a CPU fallback of the loss path.
+`GLR_FUSED_BN=0` switches the kernels off (A/B measurements)."""
+
+import os
+
+import torch
+import torch.nn.functional as F
+
+from .. import _native as N
+
+ENABLED = os.environ.get("GLR_FUSED_BN", "1") != "0"
+
+_WS = {}            # device index -> fp32 workspace for the partial sums (all launches of a device share one stream order)
+
+
+def _workspace(dev, n):
+    ws = _WS.get(dev.index)
+    if ws is None or ws.numel() < n:
+        ws = torch.empty(max(n, 1 << 20), dtype=torch.float32, device=dev)
+        _WS[dev.index] = ws
+    return ws
+
+
+class _BNAct(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, residual, weight, bias, run_mean, run_var, eps, momentum, relu):
+        L = N.lib()
+        n, c, h, w = x.shape
+        R = n * h * w
+        dev = x.device
+        y = torch.empty_like(x)                              # channels_last like x
+        stats = torch.empty(2, c, dtype=torch.float32, device=dev)
+        ws = _workspace(dev, L.glr_bn_workspace_floats(R, c))
+        N.check(L.glr_bn_act_fwd(N.ptr(x), N.ptr(residual), N.ptr(weight), N.ptr(bias), R, c, float(eps), float(momentum),
+                                 1 if relu else 0, N.ptr(run_mean), N.ptr(run_var), N.ptr(stats[0]), N.ptr(stats[1]),
+                                 N.ptr(ws), N.ptr(y), N.stream()), "glr_bn_act_fwd")
+        ctx.save_for_backward(x, y if residual is not None else None, weight, bias, stats)
+        ctx.relu, ctx.has_res = bool(relu), residual is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, weight, bias, stats = ctx.saved_tensors
+        L = N.lib()
+        n, c, h, w = x.shape
+        R = n * h * w
+        dev = x.device
+        if dy.dtype != torch.bfloat16 or not dy.is_contiguous(memory_format=torch.channels_last):
+            dy = dy.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        dx = torch.empty_like(x)
+        dres = torch.empty_like(x) if ctx.has_res else None
+        out = torch.empty(4, c, dtype=torch.float32, device=dev)
+        ws = _workspace(dev, L.glr_bn_workspace_floats(R, c))
+        N.check(L.glr_bn_act_bwd(N.ptr(x), N.ptr(dy), N.ptr(y), N.ptr(weight), N.ptr(bias), N.ptr(stats[0]), N.ptr(stats[1]),
+                                 R, c, 1 if ctx.relu else 0, 1 if ctx.has_res else 0, N.ptr(ws), N.ptr(out), N.ptr(dx),
+                                 N.ptr(dres), N.stream()), "glr_bn_act_bwd")
+        return dx, dres, out[0], out[1], None, None, None, None, None
+
+
+def _fusable(bn, x, residual):
+    c = x.shape[1] if x.dim() == 4 else 0
+    return (ENABLED and x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4 and bn.training and bn.affine
+            and bn.track_running_stats and bn.momentum is not None and 8 <= c <= 2048 and (c & (c - 1)) == 0
+            and bn.weight.dtype == torch.float32 and bn.bias.dtype == torch.float32
+            and x.is_contiguous(memory_format=torch.channels_last)
+            and (residual is None or (residual.dtype == torch.bfloat16 and residual.shape == x.shape
+                                      and residual.is_contiguous(memory_format=torch.channels_last))))
+
+
+def fused_bn_act(bn, x, residual=None, relu=True):
+    """relu?(bn(x) (+ residual)) with nn.BatchNorm2d `bn`'s parameters and running statistics."""
+    if _fusable(bn, x, residual):
+        bn.num_batches_tracked.add_(1)
+        return _BNAct.apply(x, residual, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, bn.momentum, relu)
+    out = bn(x)
+    if residual is not None:
+        out = out + residual
+    return F.relu(out) if relu else out

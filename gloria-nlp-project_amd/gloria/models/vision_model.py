@@ -10,6 +10,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import cnn_backbones
+from .fused_bn import fused_bn_act
 
 
 class ImageEncoder(nn.Module):
@@ -46,7 +47,7 @@ class ImageEncoder(nn.Module):
     def resnet_forward(self, x, extract_features=False):
         x = F.interpolate(x, size=(299, 299), mode="bilinear", align_corners=True)
         m = self.model
-        x = m.maxpool(m.relu(m.bn1(m.conv1(x))))         # (B, 64, 75, 75)
+        x = m.maxpool(fused_bn_act(m.bn1, m.conv1(x)))         # (B, 64, 75, 75)
         x = m.layer1(x)                                  # (B, 256, 75, 75)
         x = m.layer2(x)                                  # (B, 512, 38, 38)
         x = m.layer3(x)                                  # (B, 1024, 19, 19)

@@ -324,6 +324,27 @@ int glr_threshold_counts(const float* pred, const uint8_t* target, const float* 
                          uint64_t* out, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Fused training-mode BatchNorm2d (+ residual add) (+ ReLU) on channels-last bf16 activations: the 53 normalisation
+ * sites of the ResNet-50 image encoder (reference: torchvision resnet50 through
+ * gloria/models/cnn_backbones.py:31-35, vision_model.py:67-86).  x / y / dy / dx / residual / dres: bf16
+ * [R = N*H*W, C] (NHWC memory), C a power of two in [8, 2048].
+ *   fwd   mean, invstd [C] out (batch statistics, biased variance + eps); run_mean / run_var updated with
+ *         `momentum` and the unbiased variance like nn.BatchNorm2d (NULL = no running statistics);
+ *         y = relu?( (x - mean) invstd gamma + beta (+ residual) )
+ *   bwd   dx; out4c = [dgamma | dbeta | 2C floats of scratch]; with a residual also dres = dy * [y > 0] (the
+ *         gradient of the skip branch), y = the forward's output
+ *   workspace: glr_bn_workspace_floats(R, C) floats (0 = shape not supported).
+ * HBM-bound: 3 (4) tensor passes forward, 5 (7) backward; fixed-order two-level reductions (bitwise reproducible).
+ */
+int glr_bn_workspace_floats(long long R, int C);
+int glr_bn_act_fwd(const void* x, const void* residual, const float* gamma, const float* beta, long long R, int C,
+                   float eps, float momentum, int relu, float* run_mean, float* run_var, float* mean, float* invstd,
+                   float* workspace, void* y, void* stream);
+int glr_bn_act_bwd(const void* x, const void* dy, const void* y, const float* gamma, const float* beta, const float* mean,
+                   const float* invstd, long long R, int C, int relu, int has_residual, float* workspace, float* out4c,
+                   void* dx, void* dres, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Image half of the collate function: replaces, for a ragged batch of single-channel images,
  *   original_tensor_to_numpy_image   gloria/datasets/mimic_for_gloria.py:36-42  (min-max -> uint8, truncating)
  *   GloriaCollateFn._resize_img      mimic_for_gloria.py:136-181   (cv2.INTER_AREA long side -> scale, zero pad)

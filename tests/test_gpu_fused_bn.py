@@ -1,0 +1,71 @@
+"""Fused BatchNorm2d (+ residual) (+ ReLU) kernels against torch's own BatchNorm2d + add + relu on the same
+channels-last bf16 tensors (the op sequence of the reference's torchvision bottleneck): outputs, input / skip /
+affine gradients, running statistics.  Reference computed in fp32 from the same bf16 inputs; tolerances are the
+bf16 output rounding (2^-8 relative) on O(1) values."""
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.mark.parametrize("n,c,h,w", [(4, 64, 38, 38), (3, 256, 19, 19), (2, 2048, 10, 10), (5, 8, 7, 5)])
+@pytest.mark.parametrize("residual,relu", [(False, True), (True, True), (False, False)])
+def test_fused_bn_matches_torch(n, c, h, w, residual, relu, monkeypatch):
+    from gloria.models import fused_bn as FB
+    monkeypatch.setattr(FB, "ENABLED", True)
+    g = torch.Generator().manual_seed(n * 1000 + c)
+    x = (torch.randn(n, c, h, w, generator=g) * 1.5 + 0.3).to(DEV).bfloat16().contiguous(memory_format=torch.channels_last)
+    r = torch.randn(n, c, h, w, generator=g).to(DEV).bfloat16().contiguous(memory_format=torch.channels_last) if residual else None
+    dy = torch.randn(n, c, h, w, generator=g).to(DEV).bfloat16().contiguous(memory_format=torch.channels_last)
+    bn = torch.nn.BatchNorm2d(c).to(DEV).train()
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(c, generator=g) + 0.5)
+        bn.bias.copy_(torch.randn(c, generator=g) * 0.2)
+    ref = torch.nn.BatchNorm2d(c).to(DEV).train()
+    ref.load_state_dict(bn.state_dict())
+
+    xa = x.clone().requires_grad_(True)
+    ra = None if r is None else r.clone().requires_grad_(True)
+    ya = FB.fused_bn_act(bn, xa, ra, relu)
+    assert ya.dtype == torch.bfloat16 and ya.is_contiguous(memory_format=torch.channels_last)
+    ya.backward(dy)
+
+    xb = x.float().requires_grad_(True)
+    rb = None if r is None else r.float().requires_grad_(True)
+    z = ref(xb)
+    if rb is not None:
+        z = z + rb
+    yb = torch.relu(z) if relu else z
+    yb.backward(dy.float())
+
+    np.testing.assert_allclose(ya.detach().float().cpu().numpy(), yb.detach().cpu().numpy(), rtol=1e-2, atol=1e-2)
+    np.testing.assert_allclose(xa.grad.float().cpu().numpy(), xb.grad.cpu().numpy(), rtol=2e-2, atol=2e-2)
+    if ra is not None:
+        np.testing.assert_allclose(ra.grad.float().cpu().numpy(), rb.grad.cpu().numpy(), rtol=1e-2, atol=1e-2)
+    scale = float(ref.weight.grad.abs().max()) + 1e-6
+    np.testing.assert_allclose(bn.weight.grad.cpu().numpy() / scale, ref.weight.grad.cpu().numpy() / scale, atol=2e-2)
+    scale = float(ref.bias.grad.abs().max()) + 1e-6
+    np.testing.assert_allclose(bn.bias.grad.cpu().numpy() / scale, ref.bias.grad.cpu().numpy() / scale, atol=2e-2)
+    np.testing.assert_allclose(bn.running_mean.cpu().numpy(), ref.running_mean.cpu().numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(bn.running_var.cpu().numpy(), ref.running_var.cpu().numpy(), rtol=1e-3, atol=1e-5)
+    assert int(bn.num_batches_tracked) == 1
+
+
+def test_fused_bn_is_deterministic_and_falls_back(monkeypatch):
+    from gloria.models import fused_bn as FB
+    monkeypatch.setattr(FB, "ENABLED", True)
+    x = torch.randn(8, 128, 19, 19, device=DEV).bfloat16().contiguous(memory_format=torch.channels_last)
+    bn = torch.nn.BatchNorm2d(128).to(DEV).train()
+    a = FB.fused_bn_act(bn, x)
+    b = FB.fused_bn_act(bn, x)
+    assert torch.equal(a, b)
+    bn.eval()                                           # eval mode: torch's BatchNorm with the running statistics
+    e = FB.fused_bn_act(bn, x)
+    np.testing.assert_allclose(e.detach().float().cpu().numpy(), torch.relu(bn(x)).detach().float().cpu().numpy())
+    xf = x.float()                                      # fp32 parity mode: torch's BatchNorm
+    bn.train()
+    f = FB.fused_bn_act(bn, xf)
+    assert f.dtype == torch.float32
