@@ -12,10 +12,10 @@
 // IS the skip connection's gradient - is written by the reduce pass and re-read by the apply pass).
 //
 // x is viewed [R = N*H*W, C], C contiguous; a thread owns 8 consecutive channels (one 16-byte load per row).
-// * reduce passes: a workgroup owns a contiguous slab of rows (sequential DRAM pages), 8 (4) independent 16-byte
-//   loads per thread in flight, ~2048 workgroups: ~128 KB in flight per CU, which is what ~6 TB/s needs at HBM
-//   latency.  Per-workgroup partial sums [n_part][2][C] are combined in a fixed order by a small second kernel:
-//   bitwise reproducible.
+// * reduce passes: as many workgroups as the chip holds at once, each walking slabs of rows round-robin with 8 (4)
+//   independent 16-byte loads per thread in flight (~100 KB per CU, what ~6 TB/s needs at HBM latency).
+//   Per-workgroup partial sums [2][C][n_part] are combined in a fixed order by a second kernel (one wave per
+//   channel): bitwise reproducible.
 // * apply passes: short workgroups (256 threads x 4 vectors), and they walk the tensor in the OPPOSITE direction of the
 //   reduce pass in front of them, so the tail the reduce pass touched last is still in the 256 MB Infinity Cache.
 #include "glr_common.h"
@@ -23,8 +23,6 @@
 namespace {
 
 constexpr int BN_NT = 256;
-constexpr int BN_WG_TARGET = 2048;        // workgroups of a reduce pass
-constexpr int BN_FIN_NT = 1024;
 
 __device__ __forceinline__ void unpack8(const uint4 u, float (&f)[8]) {
   const unsigned w[4] = {u.x, u.y, u.z, u.w};
@@ -51,7 +49,7 @@ __global__ void __launch_bounds__(BN_NT) k_bn_reduce(const unsigned short* __res
                                                      const unsigned short* __restrict__ y, const float* __restrict__ mean,
                                                      const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, long long R, int C, int relu,
-                                                     long long rows_per_part, float* __restrict__ part,
+                                                     int n_part, float* __restrict__ part,
                                                      unsigned short* __restrict__ dz_out) {
   constexpr int UN = MODE == 0 ? 8 : 4;
   const int cg_per_blk = min(C / 8, 32), rl_per_blk = BN_NT / cg_per_blk;
@@ -67,9 +65,11 @@ __global__ void __launch_bounds__(BN_NT) k_bn_reduce(const unsigned short* __res
       sh[i] = beta[c0 + i] - mu[i] * sc[i];          // z = fma(x, sc, sh): the forward's own expression (same mask)
     }
   }
-  const long long r_begin = (long long)blockIdx.y * rows_per_part;
-  const long long r_end = min(R, r_begin + rows_per_part);
-  for (long long r = r_begin + rl; r < r_end; r += (long long)UN * rl_per_blk) {
+  // slabs of UN * rl_per_blk consecutive rows (one unrolled step of the workgroup = 8..32 KB of contiguous memory),
+  // dealt round-robin to the gridDim.y workgroups of this channel block: every workgroup finishes at the same time
+  const long long r_end = R;
+  const long long slab = (long long)UN * rl_per_blk;
+  for (long long r = (long long)blockIdx.y * slab + rl; r < r_end; r += slab * gridDim.y) {
     uint4 xr[UN], dr[UN], yr[UN];
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
@@ -117,30 +117,35 @@ __global__ void __launch_bounds__(BN_NT) k_bn_reduce(const unsigned short* __res
     const int col = threadIdx.x, tcg = col >> 3, ti = col & 7;
     float s0 = 0.f, s1 = 0.f;
     for (int k = 0; k < rl_per_blk; ++k) { s0 += red[0][k * cg_per_blk + tcg][ti]; s1 += red[1][k * cg_per_blk + tcg][ti]; }
-    part[((size_t)blockIdx.y * 2 + 0) * C + (size_t)blockIdx.x * ncol + col] = s0;
-    part[((size_t)blockIdx.y * 2 + 1) * C + (size_t)blockIdx.x * ncol + col] = s1;
+    const size_t ch = (size_t)blockIdx.x * ncol + col;
+    part[ch * n_part + blockIdx.y] = s0;                       // [2][C][n_part]: the second stage reads along the parts
+    part[((size_t)C + ch) * n_part + blockIdx.y] = s1;
   }
 }
 
-// second stage: fixed-order sums of the partials in double, 32 channels x 32 part lanes per workgroup
+// second stage: one wave per channel sums the channel's partials of both quantities (lane-strided, then a fixed
+// butterfly) in double
 //   FWD: mean / invstd (+ running statistics, momentum form of nn.BatchNorm2d)
 //   BWD: dgamma, dbeta and the two per-channel means the dx formula needs
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
 template <bool FWD>
-__global__ void __launch_bounds__(BN_FIN_NT) k_bn_finish(const float* __restrict__ part, int n_part, int C, long long R, float eps,
-                                                         float momentum, float* __restrict__ o0, float* __restrict__ o1,
-                                                         float* __restrict__ o2, float* __restrict__ o3) {
-  __shared__ double red[2][32][33];
-  const int cl = threadIdx.x & 31, pl = threadIdx.x >> 5;
-  const int c = blockIdx.x * 32 + cl;
+__global__ void __launch_bounds__(BN_NT) k_bn_finish(const float* __restrict__ part, int n_part, int C, long long R, float eps,
+                                                     float momentum, float* __restrict__ o0, float* __restrict__ o1,
+                                                     float* __restrict__ o2, float* __restrict__ o3) {
+  const int lane = threadIdx.x & 63;
+  const int c = blockIdx.x * (BN_NT / 64) + (threadIdx.x >> 6);
+  if (c >= C) return;
+  const float* p0 = part + (size_t)c * n_part;
+  const float* p1 = part + ((size_t)C + c) * n_part;
   double s = 0.0, ss = 0.0;
-  if (c < C)
-    for (int k = pl; k < n_part; k += 32) { s += (double)part[((size_t)k * 2) * C + c]; ss += (double)part[((size_t)k * 2 + 1) * C + c]; }
-  red[0][pl][cl] = s;
-  red[1][pl][cl] = ss;
-  __syncthreads();
-  if (pl != 0 || c >= C) return;
-  s = 0.0; ss = 0.0;
-  for (int k = 0; k < 32; ++k) { s += red[0][k][cl]; ss += red[1][k][cl]; }
+  for (int k = lane; k < n_part; k += 64) { s += (double)p0[k]; ss += (double)p1[k]; }
+  s = wave_sum(s);
+  ss = wave_sum(ss);
+  if (lane != 0) return;
   if (FWD) {
     const double m = s / (double)R;
     double var = ss / (double)R - m * m;
@@ -251,20 +256,34 @@ __global__ void __launch_bounds__(BN_NT) k_bn_bwd_apply(const unsigned short* __
   }
 }
 
-struct BnPlan { int cg_per_blk, col_blocks, n_part; long long rows_per_part; };
+struct BnPlan { int cg_per_blk, col_blocks, n_part; };
 
-BnPlan bn_plan(long long R, int C) {
+// workgroups of a reduce pass = what the chip holds AT ONCE (CUs x resident workgroups of that kernel: a grid-stride
+// pass with one and a bit rounds of workgroups ends with most of the chip idle), split over the channel blocks;
+// never more parts than slabs
+constexpr int BN_MAX_WG = 2048;
+int bn_resident(const void* fn) {
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    int dev = 0;
+    hipDeviceProp_t pr;
+    n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ? pr.multiProcessorCount : 256;
+  }
+  int occ = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, BN_NT, 0) != hipSuccess || occ < 1) occ = 2;
+  const int n = n_cu * occ;
+  return n > BN_MAX_WG ? BN_MAX_WG : n;
+}
+BnPlan bn_plan(long long R, int C, int resident, int un) {
   BnPlan p;
   p.cg_per_blk = C / 8 < 32 ? C / 8 : 32;
   p.col_blocks = (C / 8) / p.cg_per_blk;
   const int rl = BN_NT / p.cg_per_blk;
-  long long want = BN_WG_TARGET / p.col_blocks;
-  const long long min_rows = (long long)rl * 8;              // at least one full unrolled step per workgroup
-  long long rpp = (R + want - 1) / want;
-  if (rpp < min_rows) rpp = min_rows;
-  rpp = (rpp + rl - 1) / rl * rl;
-  p.rows_per_part = rpp;
-  p.n_part = (int)((R + rpp - 1) / rpp);
+  long long want = resident / p.col_blocks;
+  const long long slabs = (R + (long long)rl * un - 1) / ((long long)rl * un);
+  if (want > slabs) want = slabs;
+  if (want < 1) want = 1;
+  p.n_part = (int)want;
   return p;
 }
 
@@ -274,7 +293,7 @@ bool bn_shape_ok(long long R, int C) { return R > 0 && C >= 8 && C <= 2048 && (C
 
 extern "C" int glr_bn_workspace_floats(long long R, int C) {
   if (!bn_shape_ok(R, C)) return 0;
-  return bn_plan(R, C).n_part * 2 * C;
+  return bn_plan(R, C, BN_MAX_WG, 1).n_part * 2 * C;          // upper bound over both directions
 }
 
 extern "C" int glr_bn_act_fwd(const void* x, const void* residual, const float* gamma, const float* beta, long long R,
@@ -282,11 +301,12 @@ extern "C" int glr_bn_act_fwd(const void* x, const void* residual, const float* 
                               float* invstd, float* workspace, void* y, void* stream) {
   if (!x || !gamma || !beta || !mean || !invstd || !workspace || !y || !bn_shape_ok(R, C)) return GLR_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-  const BnPlan pl = bn_plan(R, C);
+  static const int res0 = bn_resident((const void*)k_bn_reduce<0, false>);
+  const BnPlan pl = bn_plan(R, C, res0, 8);
   hipLaunchKernelGGL((k_bn_reduce<0, false>), dim3(pl.col_blocks, pl.n_part), dim3(BN_NT), 0, st, (const unsigned short*)x,
-                     nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, R, C, 0, pl.rows_per_part, workspace, nullptr);
+                     nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, R, C, 0, pl.n_part, workspace, nullptr);
   GLR_CHECK_LAUNCH();
-  hipLaunchKernelGGL((k_bn_finish<true>), dim3((C + 31) / 32), dim3(BN_FIN_NT), 0, st, workspace, pl.n_part, C, R, eps, momentum,
+  hipLaunchKernelGGL((k_bn_finish<true>), dim3((C + 3) / 4), dim3(BN_NT), 0, st, workspace, pl.n_part, C, R, eps, momentum,
                      mean, invstd, run_mean, run_var);
   GLR_CHECK_LAUNCH();
   const long long n_vec = R * C / 8;
@@ -310,17 +330,19 @@ extern "C" int glr_bn_act_bwd(const void* x, const void* dy, const void* y, cons
       (has_residual && (!y || !dres)))
     return GLR_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-  const BnPlan pl = bn_plan(R, C);
+  static const int res1 = bn_resident((const void*)k_bn_reduce<1, false>);
+  static const int res2 = bn_resident((const void*)k_bn_reduce<1, true>);
+  const BnPlan pl = bn_plan(R, C, has_residual ? res2 : res1, 4);
   const dim3 rgrid(pl.col_blocks, pl.n_part);
   if (has_residual)
     hipLaunchKernelGGL((k_bn_reduce<1, true>), rgrid, dim3(BN_NT), 0, st, (const unsigned short*)x, (const unsigned short*)dy,
-                       (const unsigned short*)y, mean, invstd, gamma, beta, R, C, relu, pl.rows_per_part, workspace,
+                       (const unsigned short*)y, mean, invstd, gamma, beta, R, C, relu, pl.n_part, workspace,
                        (unsigned short*)dres);
   else
     hipLaunchKernelGGL((k_bn_reduce<1, false>), rgrid, dim3(BN_NT), 0, st, (const unsigned short*)x, (const unsigned short*)dy,
-                       nullptr, mean, invstd, gamma, beta, R, C, relu, pl.rows_per_part, workspace, nullptr);
+                       nullptr, mean, invstd, gamma, beta, R, C, relu, pl.n_part, workspace, nullptr);
   GLR_CHECK_LAUNCH();
-  hipLaunchKernelGGL((k_bn_finish<false>), dim3((C + 31) / 32), dim3(BN_FIN_NT), 0, st, workspace, pl.n_part, C, R, 0.f, 0.f, out4c,
+  hipLaunchKernelGGL((k_bn_finish<false>), dim3((C + 3) / 4), dim3(BN_NT), 0, st, workspace, pl.n_part, C, R, 0.f, 0.f, out4c,
                      out4c + C, out4c + 2 * C, out4c + 3 * C);
   GLR_CHECK_LAUNCH();
   const long long n_vec = R * C / 8;
