@@ -43,6 +43,9 @@
 
 #include "glr_common.h"
 
+#ifndef GLR_BWD_CUT
+#define GLR_BWD_CUT 0
+#endif
 #ifndef GLR_STAGGER
 #define GLR_STAGGER 1
 #endif
@@ -96,6 +99,7 @@ struct LaParams {
   unsigned char* aout;          // [B_img][n_slots][S_pad] a2
   float* gamma;                 // [B_img][n_slots]
   float* beta;                  // [B_img][n_slots]
+  unsigned char* baout;         // optional [B_img][n_slots][S_pad] beta * a2 (the P3 operand image)
   // LDS carve (bytes)
   int off_img, off_small;
 #ifdef GLR_STAMPS
@@ -648,6 +652,16 @@ __global__ void __launch_bounds__(NTHR) k_local_attn(LaParams p) {
                          nrb, tw);
 
     GLR_STAMP(4);
+    if (BWD && p.baout != nullptr && sweep == 1) {
+      // third output: the operand image beta a2 (rows >= tw of the tile are zero)
+      const int rowb = S_pad * ESZ, ppr = rowb >> 4;
+      for (int i = tid; i < TW * ppr; i += NTHR) {
+        const int row = i / ppr, pc = i % ppr;
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (row < tw) v = *reinterpret_cast<const uint4*>(img + row * IMP + pc * 16);
+        *reinterpret_cast<uint4*>(p.baout + ((size_t)b * p.n_slots + (size_t)tile * TW + row) * rowb + pc * 16) = v;
+      }
+    }
     if (!BWD) {
       // |c~|^2 = sum_r e2[w, r] * u~[w, r]
 #pragma unroll
@@ -1270,6 +1284,331 @@ __global__ void __launch_bounds__(NTHR) k_local_attn_pw(LaParams p) {
 #undef GLR_SGK
 }
 
+// ------------------------------------------------------------------------------------------
+// Backward for a PAIR of tiles, wave-owned words: the forward pair kernel's decomposition (same descriptor, same
+// streams, same lane -> (word row, region) mapping) applied to autograd through gloria_loss.py:19-63, 150-164.
+//   set-up  per-word scalars (alpha, beta, kappa, 1/Z: float4 per slot) from dsim and the forward's statistics;
+//           the lse rows of the pair's sentences -> LDS (log2 units).  Their global loads are issued before the
+//           score stream and consumed after it.
+//   P1      acc = s = T V^T                                  (stream of vt[b], both tiles)
+//   P2      a1 = exp2(s log2e - lse), a2 = exp2(temp1 log2e a1) / Z; image = bf16(beta a2); acc = -alpha s;
+//           a1 stays in registers as fp16 pairs (48 registers; fp32 copies do not fit beside 96 accumulators)
+//   P3      acc += image . G^T = beta u - alpha s = -da2      (stream of gram[b])
+//   A       da1 = temp1 a2 (da2 - kappa); run sums of a1 da1 per (sentence, region) -> one-writer half tables
+//           (no LDS atomics); acc = a1 da1 + alpha a2; image = bf16(a2) -> aout (16-byte row stores)
+//   B       rho = fixed-order sum of the half tables (and of the other tile's row for a spanning sentence);
+//           X = acc - a1 rho -> image -> xout
+// Optional third output baout = the P3 operand image beta a2 (saves the caller an elementwise pass in front of the
+// P = (beta a2)^T a2 GEMM).  Empty word slots have zero scalars: their rows of every output are exact zeros.
+template <typename O>
+__global__ void __launch_bounds__(NTHR) k_local_attn_pw_bwd(LaParams p) {
+  constexpr int ESZ = O::ESZ, CB = CHB;
+  constexpr int SP = GLR_MAX_SPAD;
+  constexpr int NRB = SP / 32;
+  constexpr int IMP = SP * ESZ + 16;
+  constexpr int IMG = TW * IMP;
+  constexpr int PPR = SP * ESZ / 16;                              // 16-byte pieces per output row
+  constexpr float LOG2E = 1.4426950408889634f;
+  constexpr int LT_OFF = NBUF * (2 * TW + SP) * CB;               // first byte past the P1 ring
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int t = wave & 1, wg = wave >> 1;
+  const int l31 = lane & 31, h = lane >> 5;
+
+  const int xcd = blockIdx.x & 7, qq = blockIdx.x >> 3;
+  const int ib = p.img_block;
+  const int grp = qq / (ib * p.n_items), rem = qq - grp * (ib * p.n_items);
+  const int b = (grp * ib + rem % ib) * 8 + xcd;
+  if (b >= p.B_img) return;
+  const int tile0 = p.item_tile[rem / ib];
+  const int D = p.D;
+
+  unsigned char* ring = smem;
+  unsigned char* img0 = smem;
+  float* rh = reinterpret_cast<float*>(smem + p.off_img);        // [2][PW_MAXSEG][SP] run sums of a1 da1 (after P3)
+  constexpr int HT = PW_MAXSEG * SP;
+  unsigned char* ring3 = smem + p.off_img;
+  float* lt = reinterpret_cast<float*>(smem + LT_OFF);           // [PW_MAXSEG][SP] lse, log2 units (P2 only)
+  signed char* wsegb = reinterpret_cast<signed char*>(smem + p.off_small);
+  int* seg_w0 = reinterpret_cast<int*>(wsegb + 2 * TW);
+  int* seg_n = seg_w0 + PW_MAXSEG;
+  int* seg_sent = seg_n + PW_MAXSEG;
+  int* misc = seg_sent + PW_MAXSEG;                              // [16..79] descriptor
+  float4* w4 = reinterpret_cast<float4*>(misc + 80);             // [2 * TW] (1/Z, beta, alpha, kappa) per word slot
+  float* zero = reinterpret_cast<float*>(w4 + 2 * TW);           // [SP] neutral second table row
+
+  const size_t rowbytes1 = (size_t)D * ESZ, rowbytes2 = (size_t)SP * ESZ;
+  const unsigned char* vt_b = p.vt + (size_t)b * SP * rowbytes1;
+  const unsigned char* gram_b = p.gram + (size_t)b * SP * rowbytes2;
+
+  int* dsc = misc + 16;
+  if (tid < 64) dsc[tid] = p.pair_desc[(size_t)(rem / ib) * 64 + tid];
+  // slot-indexed statistics do not depend on the descriptor: first round trip
+  float4 ws = make_float4(0.f, 0.f, 0.f, 0.f);
+  float tn = 0.f;
+  if (tid < 2 * TW) {
+    wsegb[tid] = -1;
+    const size_t slot = (size_t)tile0 * TW + tid;
+    ws = *reinterpret_cast<const float4*>(p.wstat + ((size_t)b * p.n_slots + slot) * WSTAT);
+    tn = p.tnorm[slot];
+  }
+  if (tid < SP) zero[tid] = 0.f;
+  __syncthreads();
+  const int NS = dsc[0];
+  const bool long_pair = dsc[1] != 0;
+  if (tid < NS) {
+    const int sent = dsc[8 + tid], w0 = dsc[16 + tid], n = dsc[24 + tid];
+    seg_sent[tid] = sent;
+    seg_w0[tid] = w0;
+    seg_n[tid] = n;
+    for (int w = 0; w < n; ++w) wsegb[w0 + w] = (signed char)tid;
+  }
+  __syncthreads();
+  // second round trip, issued here and consumed behind the score stream: dsim / sim of the slot's sentence, and the
+  // lse rows of the pair's sentences (6 coalesced values per thread)
+  float gsim = 0.f, vsim = 0.f;
+  int sgw = -1;
+  if (tid < 2 * TW) {
+    sgw = wsegb[tid];
+    if (sgw >= 0) {
+      const size_t o = (size_t)b * p.ld_sim + seg_sent[sgw];
+      gsim = p.dsim[o];
+      vsim = p.sim[o];
+    }
+  }
+  float lpre[PW_MAXSEG * SP / NTHR];
+#pragma unroll
+  for (int i = 0; i < PW_MAXSEG * SP / NTHR; ++i) {
+    const int e = tid + i * NTHR, s2 = e / SP, r = e - s2 * SP;
+    lpre[i] = s2 < NS ? p.lse[((size_t)b * p.n_sent + dsc[8 + s2]) * SP + r] : 0.f;
+  }
+
+#pragma unroll
+  for (int i = 0; i < PW_MAXSEG * SP / NTHR; ++i) lt[tid + i * NTHR] = lpre[i] * LOG2E;
+  if (tid < 2 * TW) {
+    // per-word scalars from dsim and the forward's saved statistics (the single-tile kernel's formulas)
+    float al = 0.f, be = 0.f, ka = 0.f, zi = 0.f, ga = 0.f;
+    if (sgw >= 0) {
+      const float Z = ws.x, cosv = ws.y, nc2 = ws.z;
+      float A = __expf(vsim / p.temp3);
+      if (p.agg == GLR_AGG_MEAN) A *= (float)seg_n[sgw];
+      const float q = gsim * p.temp3 * p.temp2 * __expf(p.temp2 * cosv) / A;
+      const float nc = sqrtf(nc2);
+      const float prod = tn * nc;
+      const float den = fmaxf(prod, p.eps);
+      al = q / den;
+      if (prod >= p.eps) { be = q * cosv / nc2; ga = q * cosv / (tn * tn); }
+      ka = al * (cosv * den) - be * nc2;
+      zi = Z > 0.f ? 1.f / Z : 0.f;
+    }
+    w4[tid] = make_float4(zi, be, al, ka);
+    const size_t slot = (size_t)tile0 * TW + tid;
+    p.gamma[(size_t)b * p.n_slots + slot] = ga;
+    p.beta[(size_t)b * p.n_slots + slot] = be;
+  }
+  __syncthreads();
+
+  // ================= P1 (both tiles, one stream of vt[b]) =================
+  f32x16 acc0[3], acc1[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) { acc0[j][q] = 0.f; acc1[j][q] = 0.f; }
+  stream_gemm<O, false, 2>(acc0, acc1, t * TW, 32 * CB, ring, (2 * TW + SP) * CB, p.tp + (size_t)tile0 * TW * rowbytes1,
+                           rowbytes1, vt_b, rowbytes1, SP, (int)(rowbytes1 / CB), nullptr, 0, wave, lane, 0, wg, NRB, TW);
+
+  const int* fl = dsc + 32 + 8 * t;
+  const unsigned ST0 = __builtin_amdgcn_readfirstlane(fl[0]), ST1 = __builtin_amdgcn_readfirstlane(fl[1]),
+                 LA0 = __builtin_amdgcn_readfirstlane(fl[2]), LA1 = __builtin_amdgcn_readfirstlane(fl[3]);
+  const unsigned STANY = ST0 | ST1, LAANY = LA0 | LA1;
+  const unsigned STh = h ? ST1 : ST0, LAh = h ? LA1 : LA0;
+#define GLR_SBIT(mask, k) __builtin_expect(([&] { unsigned b_ = ((mask) >> (k)) & 1u; asm volatile("" : "+s"(b_)); return b_ != 0; }()), 0)
+  int sgp[8];
+#pragma unroll
+  for (int g = 0; g < 8; ++g) sgp[g] = *reinterpret_cast<const int*>(wsegb + t * TW + (g >> 2) * 32 + 4 * h + 8 * (g & 3));
+#define GLR_SGK(k) ((sgp[(k) >> 2] << (24 - 8 * ((k) & 3))) >> 24)
+  const int rbase = wg * 32 + l31;
+  const float t1l = p.temp1 * LOG2E;
+  const float ok2 = (rbase + 256 < p.S_eff) ? 1.f : 0.f;          // padded regions live in block 2 only
+  unsigned a1k0[3][8], a1k1[3][8];                                // a1 as fp16 pairs (rows q, q + 1)
+  unsigned char* imgw = img0 + t * IMG + (4 * h) * IMP + rbase * ESZ;
+  const float4* w4t = w4 + t * TW + 4 * h;
+
+  // ================= P2 =================
+  {
+    float lc[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk) {
+      f32x16(&acc)[3] = blk == 0 ? acc0 : acc1;
+      unsigned(&a1k)[3][8] = blk == 0 ? a1k0 : a1k1;
+      float a1e[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int k = blk * 16 + q;
+        const int row = blk * 32 + (q & 3) + 8 * (q >> 2);
+        if (GLR_SBIT(STANY, k)) {
+          const bool mine = (STh >> k) & 1;
+          const float* src = lt + (long_pair ? 0 : max(GLR_SGK(k), 0)) * SP + rbase;
+#pragma unroll
+          for (int j = 0; j < 3; ++j) {
+            const float l2 = src[128 * j];
+            lc[j] = mine ? l2 : lc[j];
+          }
+        }
+        const float4 w = w4t[row];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          float x = __builtin_fmaf(acc[j][q], LOG2E, -lc[j]);
+          asm("v_min_f32 %0, 0, %1" : "=v"(x) : "v"(x));          // empty slots: stale lse, keep a1 finite
+          const float a1 = __builtin_amdgcn_exp2f(x);
+          const float a2 = __builtin_amdgcn_exp2f(t1l * a1) * w.x;
+          O::from_f32(imgw + row * IMP + 128 * j * ESZ, w.y * a2);
+          // (volatile: the compiler otherwise sinks the conversion to its use behind P3 and keeps - spills - 96 fp32 values)
+          if (q & 1) asm volatile("v_cvt_pkrtz_f16_f32 %0, %1, %2" : "=v"(a1k[j][q >> 1]) : "v"(a1e[j]), "v"(a1));
+          else a1e[j] = a1;
+          acc[j][q] = -w.z * acc[j][q];
+          asm volatile("" : "+v"(acc[j][q]));                   // computed HERE (not sunk to its use behind the barrier)
+        }
+      }
+    }
+  }
+  __syncthreads();                              // images complete; lt is dead: the P3 ring takes its place
+#if GLR_BWD_CUT == 1
+  { float u_ = 0.f; unsigned x_ = 0;
+_Pragma("unroll") for (int j = 0; j < 3; ++j) { _Pragma("unroll") for (int q = 0; q < 16; ++q) { u_ += acc0[j][q] * acc1[j][q]; x_ ^= a1k0[j][q >> 1] + a1k1[j][q >> 1] * (q + 1); } }
+    p.gamma[tid] = u_ + __uint_as_float(x_); return; }
+#endif
+
+  // ================= P3: acc += (beta a2) . G^T =================
+  stream_gemm<O, true, 2, 2>(acc0, acc1, 0, 32 * IMP, ring3, SP * CB, nullptr, 0, gram_b, rowbytes2, SP,
+                            (int)(rowbytes2 / CB), img0 + t * IMG, IMP, wave, lane, 0, wg, NRB, TW);
+
+#if GLR_BWD_CUT == 2
+  { float u_ = 0.f; unsigned x_ = 0;
+_Pragma("unroll") for (int j = 0; j < 3; ++j) { _Pragma("unroll") for (int q = 0; q < 16; ++q) { u_ += acc0[j][q] * acc1[j][q]; x_ ^= a1k0[j][q >> 1] + a1k1[j][q >> 1] * (q + 1); } }
+    p.gamma[tid] = u_ + __uint_as_float(x_); return; }
+#endif
+  if (p.baout != nullptr) {
+    // the operand image beta a2 itself is the third output
+    for (int i = tid; i < 2 * TW * PPR; i += NTHR) {
+      const int row = i / PPR, pc = i - row * PPR;
+      const uint4 v = *reinterpret_cast<const uint4*>(img0 + (row >> 6) * IMG + (row & 63) * IMP + pc * 16);
+      *reinterpret_cast<uint4*>(p.baout + ((size_t)b * p.n_slots + (size_t)tile0 * TW + row) * (SP * ESZ) + pc * 16) = v;
+    }
+    __syncthreads();
+  }
+
+  // ================= A: da1, run sums of a1 da1, a2 image =================
+  const int nrow = long_pair ? 2 : NS;
+  {
+    float* tz = rh + h * HT + rbase;
+    for (int s2 = 0; s2 < nrow; ++s2) {
+      if ((long_pair ? s2 : (seg_w0[s2] >> 6)) != t) continue;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) tz[s2 * SP + 128 * j] = 0.f;
+    }
+  }
+  {
+    float rs[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 32; ++k) {
+      f32x16(&acc)[3] = k < 16 ? acc0 : acc1;
+      const unsigned(&a1k)[3][8] = k < 16 ? a1k0 : a1k1;
+      const int q = k & 15;
+      const int row = (k >> 4) * 32 + (q & 3) + 8 * (q >> 2);
+      const float4 w = w4t[row];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const h2 hp = __builtin_bit_cast(h2, a1k[j][q >> 1]);
+        const float a1 = (float)((q & 1) ? hp.y : hp.x);
+        const float a2 = __builtin_amdgcn_exp2f(t1l * a1) * w.x;
+        const float da1 = p.temp1 * a2 * (-acc[j][q] - w.w);
+        const float pr = a1 * da1;
+        rs[j] += pr;
+        acc[j][q] = __builtin_fmaf(w.z, a2, pr);
+        asm volatile("" : "+v"(acc[j][q]));
+        O::from_f32(imgw + row * IMP + 128 * j * ESZ, j == 2 ? ok2 * a2 : a2);
+      }
+      if (GLR_SBIT(LAANY, k)) {
+        const bool mine = (LAh >> k) & 1;
+        if (mine) {
+          float* dst = rh + h * HT + (long_pair ? t : GLR_SGK(k)) * SP + rbase;
+#pragma unroll
+          for (int j = 0; j < 3; ++j) dst[128 * j] = rs[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) rs[j] = mine ? 0.f : rs[j];
+      }
+    }
+  }
+  __syncthreads();                              // a2 images and the run-sum tables (both tiles) are complete
+#if GLR_BWD_CUT == 3
+  { float u_ = 0.f; unsigned x_ = 0;
+_Pragma("unroll") for (int j = 0; j < 3; ++j) { _Pragma("unroll") for (int q = 0; q < 16; ++q) { u_ += acc0[j][q] * acc1[j][q]; x_ ^= a1k0[j][q >> 1] + a1k1[j][q >> 1] * (q + 1); } }
+    p.gamma[tid] = u_ + __uint_as_float(x_); return; }
+#endif
+  for (int i = tid; i < 2 * TW * PPR; i += NTHR) {
+    const int row = i / PPR, pc = i - row * PPR;
+    const uint4 v = *reinterpret_cast<const uint4*>(img0 + (row >> 6) * IMG + (row & 63) * IMP + pc * 16);
+    *reinterpret_cast<uint4*>(p.aout + ((size_t)b * p.n_slots + (size_t)tile0 * TW + row) * (SP * ESZ) + pc * 16) = v;
+  }
+
+  // ================= B: X = acc - a1 rho (registers), then through the image to xout =================
+  // (opaque copies: the compiler otherwise keeps pass A's unpacked fp32 a1 alive - spilled - for this pass)
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { asm volatile("" : "+v"(a1k0[j][i])); asm volatile("" : "+v"(a1k1[j][i])); }
+  {
+    const float* r1 = (long_pair ? rh + SP : zero) + rbase;      // second row: the other tile's (spanning sentence) or zeros
+    const int HT2 = long_pair ? HT : 0;
+    float rc[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 32; ++k) {
+      f32x16(&acc)[3] = k < 16 ? acc0 : acc1;
+      const unsigned(&a1k)[3][8] = k < 16 ? a1k0 : a1k1;
+      const int q = k & 15;
+      if (GLR_SBIT(STANY, k)) {
+        const bool mine = (STh >> k) & 1;
+        const float* r0 = rh + (long_pair ? 0 : max(GLR_SGK(k), 0)) * SP + rbase;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          const float rho = (r0[128 * j] + r0[HT + 128 * j]) + (r1[128 * j] + r1[HT2 + 128 * j]);
+          rc[j] = mine ? rho : rc[j];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const h2 hp = __builtin_bit_cast(h2, a1k[j][q >> 1]);
+        const float a1 = (float)((q & 1) ? hp.y : hp.x);
+        const float x = __builtin_fmaf(-a1, rc[j], acc[j][q]);
+        acc[j][q] = j == 2 ? ok2 * x : x;
+        asm volatile("" : "+v"(acc[j][q]));
+      }
+    }
+  }
+#undef GLR_SBIT
+#undef GLR_SGK
+  __syncthreads();                              // every thread has read its a2 rows out of the image
+#pragma unroll
+  for (int k = 0; k < 32; ++k) {
+    const f32x16(&acc)[3] = k < 16 ? acc0 : acc1;
+    const int q = k & 15;
+    const int row = (k >> 4) * 32 + (q & 3) + 8 * (q >> 2);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) O::from_f32(imgw + row * IMP + 128 * j * ESZ, acc[j][q]);
+  }
+  __syncthreads();
+  for (int i = tid; i < 2 * TW * PPR; i += NTHR) {
+    const int row = i / PPR, pc = i - row * PPR;
+    const uint4 v = *reinterpret_cast<const uint4*>(img0 + (row >> 6) * IMG + (row & 63) * IMP + pc * 16);
+    *reinterpret_cast<uint4*>(p.xout + (((size_t)tile0 * TW + row) * p.B_img + b) * (SP * ESZ) + pc * 16) = v;
+  }
+}
+
 #ifdef GLR_STAMPS
 unsigned long long* g_stamps = nullptr;
 unsigned long long* g_stamps2 = nullptr;
@@ -1351,6 +1690,23 @@ int launch_pair(LaParams& p, int op_dtype, void* stream) {
   return GLR_OK;
 }
 
+int launch_pair_bwd(LaParams& p, int op_dtype, void* stream) {
+  if (op_dtype != GLR_BF16 || p.S_pad != GLR_MAX_SPAD) return GLR_EINVAL;
+  if (p.damean != nullptr || p.dattn != nullptr) return GLR_EINVAL;   // the extra gradient inputs take the single-tile kernel
+  const int lds = carve_pair(p, op_dtype, p.S_pad);
+  // lse table behind the P1 ring, in front of the small area
+  if (lds > 160 * 1024 || NBUF * (2 * TW + p.S_pad) * CHB + PW_MAXSEG * p.S_pad * 4 > p.off_small) return GLR_EINVAL;
+  static const int env_ib = [] { const char* e = getenv("GLR_K1_IMG_BLOCK"); return e ? atoi(e) : 0; }();
+  p.img_block = env_ib > 0 ? env_ib : 4;
+  const int per_xcd = ((p.B_img + 7) / 8 + p.img_block - 1) / p.img_block * p.img_block;
+  const int grid = per_xcd * 8 * p.n_items;
+  if (p.pair_desc == nullptr || p.S_eff >= p.S_pad) return GLR_EINVAL;
+  if (hipFuncSetAttribute((const void*)k_local_attn_pw_bwd<OpBF16>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return GLR_ELAUNCH;
+  hipLaunchKernelGGL((k_local_attn_pw_bwd<OpBF16>), dim3(grid), dim3(NTHR), lds, (hipStream_t)stream, p);
+  GLR_CHECK_LAUNCH();
+  return GLR_OK;
+}
+
 int fill_common(LaParams& p, const void* vt, const void* gram, const void* tp, const float* tnorm,
                 const int32_t* sent_slot0, const int32_t* cap_lens, const int32_t* tile_first, const int32_t* order,
                 const int32_t* tile_nsub, int n_tiles, int n_sent, int B_img, int D, int S_eff, float temp1,
@@ -1369,7 +1725,7 @@ int fill_common(LaParams& p, const void* vt, const void* gram, const void* tp, c
   p.eps = eps;
   p.tw = glr_tile_capacity(op_dtype);
   p.attn = nullptr; p.attn_off = nullptr; p.strip = 0; p.pair_only = 0; p.img_offset = 0;
-  p.dsim = nullptr; p.xout = nullptr; p.aout = nullptr; p.gamma = nullptr; p.beta = nullptr;
+  p.dsim = nullptr; p.xout = nullptr; p.aout = nullptr; p.gamma = nullptr; p.beta = nullptr; p.baout = nullptr;
   p.lse = nullptr; p.wstat = nullptr; p.sim = nullptr; p.ld_sim = 0;
 #ifdef GLR_STAMPS
   p.stamps = g_stamps;
@@ -1415,25 +1771,38 @@ extern "C" int glr_local_attn_fwd(const void* vt, const void* gram, const void* 
 extern "C" int glr_local_attn_bwd(const void* vt, const void* gram, const void* tp, const float* tnorm,
                                   const int32_t* sent_slot0, const int32_t* cap_lens,
                                   const int32_t* tile_first, const int32_t* order, const int32_t* tile_nsub,
-                                  const int32_t* item_tile, int n_items, int n_tiles, int n_sent, int B_img, int D,
+                                  const int32_t* single_tile, int n_single, const int32_t* pair_tile, int n_pair,
+                                  const int32_t* pair_desc, int n_tiles, int n_sent, int B_img, int D,
                                   int S_eff, float temp1, float temp2, float temp3, int agg, float eps,
                                   const float* sim, const float* dsim, int ld_sim, const float* lse,
                                   const float* wstat, const float* damean, const float* dattn,
                                   const int64_t* attn_off, int strip, int img_offset, void* xout, void* aout,
-                                  float* gamma, float* beta, int op_dtype, void* stream) {
+                                  void* baout, float* gamma, float* beta, int op_dtype, void* stream) {
   LaParams p;
-  const int rc = fill_common(p, vt, gram, tp, tnorm, sent_slot0, cap_lens, tile_first, order, tile_nsub, n_tiles,
-                             n_sent, B_img, D, S_eff, temp1, temp2, temp3, agg, eps, op_dtype);
+  int rc = fill_common(p, vt, gram, tp, tnorm, sent_slot0, cap_lens, tile_first, order, tile_nsub, n_tiles,
+                       n_sent, B_img, D, S_eff, temp1, temp2, temp3, agg, eps, op_dtype);
   if (rc != GLR_OK) return rc;
-  if (!sim || !dsim || !lse || !wstat || !xout || !aout || !gamma || !beta || !item_tile || n_items <= 0) return GLR_EINVAL;
+  if (!sim || !dsim || !lse || !wstat || !xout || !aout || !gamma || !beta) return GLR_EINVAL;
+  if (n_single < 0 || n_pair < 0 || n_single + n_pair == 0 || (n_single > 0 && !single_tile) || (n_pair > 0 && (!pair_tile || !pair_desc)))
+    return GLR_EINVAL;
   if (agg == GLR_AGG_MAX) return GLR_EINVAL;      // max aggregation is inference-only (gloria_model.py:199)
   p.sim = const_cast<float*>(sim); p.dsim = dsim; p.ld_sim = ld_sim; p.lse = const_cast<float*>(lse);
   p.wstat = const_cast<float*>(wstat); p.xout = (unsigned char*)xout; p.aout = (unsigned char*)aout;
+  p.baout = (unsigned char*)baout;
   if (dattn && !attn_off) return GLR_EINVAL;
   if (img_offset < 0 || img_offset + B_img > n_sent) return GLR_EINVAL;
-  p.gamma = gamma; p.beta = beta; p.item_tile = item_tile; p.n_items = n_items; p.damean = damean;
+  p.gamma = gamma; p.beta = beta; p.damean = damean;
   p.dattn = dattn; p.attn_off = (const long long*)attn_off; p.strip = strip; p.img_offset = img_offset;
-  return launch<true>(p, op_dtype, stream);
+  if (n_single > 0) {
+    p.item_tile = single_tile; p.n_items = n_single;
+    rc = launch<true>(p, op_dtype, stream);
+    if (rc != GLR_OK) return rc;
+  }
+  if (n_pair > 0) {
+    p.item_tile = pair_tile; p.n_items = n_pair; p.pair_desc = pair_desc;
+    rc = launch_pair_bwd(p, op_dtype, stream);
+  }
+  return rc;
 }
 
 #ifdef GLR_STAMPS

@@ -137,8 +137,9 @@ def _pack_operands(img_features, words, no_attn_vec, cap_lens, o):
 def _k1_args(plan, vt, gram, tp, tnorm, B, D, s_eff, o, backward=False):
     head = (N.ptr(vt), N.ptr(gram), N.ptr(tp), N.ptr(tnorm), N.ptr(plan.sent_slot0), N.ptr(plan.cap_lens),
             N.ptr(plan.tile_first), N.ptr(plan.order), N.ptr(plan.tile_nsub))
-    if backward:
-        items = (N.ptr(plan.all_tile), plan.n_all)
+    if backward == "all_single":
+        # extra gradient inputs (regulariser rows / attention maps): every tile through the single-tile kernel
+        items = (N.ptr(plan.all_tile), plan.n_all, None, 0, None)
     else:
         items = (N.ptr(plan.single_tile) if plan.n_single else None, plan.n_single,
                  N.ptr(plan.pair_tile) if plan.n_pair else None, plan.n_pair, N.ptr(plan.pair_desc))
@@ -234,20 +235,22 @@ class LocalSimFn(torch.autograd.Function):
             ns = plan.n_slots
             xout = torch.empty(ns, B, s_pad, dtype=odt, device=dev)
             aout = torch.empty(B, ns, s_pad, dtype=odt, device=dev)
+            baout = torch.empty(B, ns, s_pad, dtype=odt, device=dev)
             gamma = torch.empty(B, ns, dtype=torch.float32, device=dev)
             beta = torch.empty(B, ns, dtype=torch.float32, device=dev)
             g = dsim.float().contiguous()
             bwd_range = _Range("k1_bwd_op")
             bwd_range.__enter__()
             with _Range("k1_bwd"):
-                N.check(L.glr_local_attn_bwd(*_k1_args(plan, vt_t, gram_t, tp_t, tnorm, B, D, s_eff, o, True), N.ptr(sim),
+                mode = "all_single" if (dam is not None or dat is not None) else True
+                N.check(L.glr_local_attn_bwd(*_k1_args(plan, vt_t, gram_t, tp_t, tnorm, B, D, s_eff, o, mode), N.ptr(sim),
                                              N.ptr(g), plan.n_sent, N.ptr(lse), N.ptr(wstat), N.ptr(dam), N.ptr(dat),
-                                             N.ptr(dat_off), strip, o.img_offset, N.ptr(xout), N.ptr(aout),
+                                             N.ptr(dat_off), strip, o.img_offset, N.ptr(xout), N.ptr(aout), N.ptr(baout),
                                              N.ptr(gamma), N.ptr(beta), code, N.stream()), "glr_local_attn_bwd")
             # gradient GEMMs (plain library GEMMs on the kernel's outputs)
             x2d = xout.view(ns, B * s_pad)
             dtp = (x2d @ vt.view(B * s_pad, D)).float() - gamma.sum(0).unsqueeze(1) * tp.float()      # [ns, D]
-            P = torch.bmm((aout * beta.unsqueeze(2).to(odt)).transpose(1, 2), aout)                    # [B, S, S]
+            P = torch.bmm(baout.transpose(1, 2), aout)                                                 # [B, S, S], baout = beta a2
             dvt = (x2d.t() @ tp).view(B, s_pad, D).float() - torch.bmm(P, vt).float()                 # [B, S, D]
             si, wi, slot = plan.word_index(dev)
             d_words.permute(0, 2, 1)[si, wi + o.word_start] = dtp[slot]

@@ -185,8 +185,12 @@ int glr_pack_words(const void* words_emb, int in_dtype, const int32_t* sent_slot
  *                dT_packed = X2d . vt2d - gamma_sum * T,   dvt2d = X2d^T . tp - P . vt
  *   aout  [B_img, n_slots, S_pad] op dtype   a2;   beta [B_img, n_slots] fp32 :
  *                P[b] = (beta[b] * aout[b])^T . aout[b]
+ *   baout [B_img, n_slots, S_pad] op dtype   optional (NULL = not wanted): beta * a2, the first factor of P, as the
+ *                kernel's own second-contraction operand holds it
  *   gamma [B_img, n_slots] fp32              coefficient of T_w in dT (from the word norm)
  * with X2d = xout viewed [n_slots, B_img*S_pad] and vt2d = vt viewed [B_img*S_pad, D].
+ * The backward takes the forward's work items: single tiles and (bf16, 384 regions, no damean / dattn) pairs with
+ * their descriptors; with damean / dattn every tile must be passed as a single tile.
  */
 int glr_local_attn_fwd(const void* vt, const void* gram, const void* tp, const float* tnorm,
                        const int32_t* sent_slot0, const int32_t* cap_lens, const int32_t* tile_first,
@@ -198,12 +202,13 @@ int glr_local_attn_fwd(const void* vt, const void* gram, const void* tp, const f
 
 int glr_local_attn_bwd(const void* vt, const void* gram, const void* tp, const float* tnorm,
                        const int32_t* sent_slot0, const int32_t* cap_lens, const int32_t* tile_first,
-                       const int32_t* order, const int32_t* tile_nsub, const int32_t* item_tile, int n_items,
+                       const int32_t* order, const int32_t* tile_nsub, const int32_t* single_tile, int n_single,
+                       const int32_t* pair_tile, int n_pair, const int32_t* pair_desc,
                        int n_tiles, int n_sent, int B_img, int D, int S_eff, float temp1, float temp2, float temp3,
                        int agg, float eps, const float* sim, const float* dsim, int ld_sim, const float* lse,
                        const float* wstat, const float* damean, const float* dattn, const int64_t* attn_off,
-                       int strip, int img_offset, void* xout, void* aout, float* gamma, float* beta, int op_dtype,
-                       void* stream);
+                       int strip, int img_offset, void* xout, void* aout, void* baout, float* gamma, float* beta,
+                       int op_dtype, void* stream);
 
 /* K-tiling of the K1 operands (device, HBM-bound copy).  glr_local_attn_fwd / _bwd take vt, gram and tp in
  * the K-TILED layout: every block of `rows` rows (vt, gram: the S_pad rows of one image; tp: the 64 slots of one

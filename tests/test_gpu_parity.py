@@ -260,8 +260,8 @@ BF16_CASES = {
     # 197 regions (S_pad 256: the non-FULL single-tile kernel in both directions), 256 / 130 / 77 words = sentences of
     # 4 / 3 / 2 word tiles (nsub > 1: two sweeps forward, multi-tile rho backward)
     "cfg5_s197_n256": (3, 768, 14, 14, 256, [256, 130, 77], True),
-    # 362 regions (S_pad 384): 96 / 70 / 65 words own a tile pair in the forward (long-pair path of the pair kernel)
-    # and run as two-tile sentences in the backward; the short ones share an ordinary pair
+    # 362 regions (S_pad 384): 96 / 70 / 65 words own a tile pair (long-pair path of the pair kernels, forward and
+    # backward); the short ones share an ordinary pair
     "ragged_s362_multitile": (6, 768, 19, 19, 97, [96, 70, 65, 33, 5, 1], True),
     "ragged_s361_pairs": (8, 768, 19, 19, 97, [40, 33, 31, 22, 17, 9, 2, 1], False),
 }

@@ -13,6 +13,7 @@ from collections import defaultdict
 FAMILIES = [
     ("K1 fwd (k_local_attn)", r"k_local_attn(_pair)?<.*(false|OpBF16)>|k_local_attn_pair"),
     ("K1 bwd (k_local_attn)", r"k_local_attn<.*true>"),
+    ("glr fused BN+ReLU (k_bn_*)", r"\(anonymous namespace\)::k_bn_"),
     ("glr other (pack/ce/global/segsum/adam)", r"\(anonymous namespace\)::k_|glr_"),
     ("conv (MIOpen igemm/ck/naive)", r"igemm|conv|Conv|gridwise_gemm|GridwiseGemm|naive"),
     ("batchnorm", r"BatchNorm|batch_norm|bn_"),
