@@ -43,9 +43,6 @@
 
 #include "glr_common.h"
 
-#ifndef GLR_BWD_CUT
-#define GLR_BWD_CUT 0
-#endif
 #ifndef GLR_STAGGER
 #define GLR_STAGGER 1
 #endif
@@ -149,6 +146,14 @@ __device__ unsigned long long* g_wave_stamps = nullptr;
 #define GLR_SKIP(bit) false
 #endif
 
+// 16-byte streaming store of a kernel output: non-temporal, so that the backward's 300 KB of outputs per workgroup do
+// not evict the operand streams (vt / gram / word tiles) the XCD's other workgroups are re-reading from L2
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void st_stream16(void* dst, const uint4 v, bool plain = false) {
+  u32x4 x = {v.x, v.y, v.z, v.w};
+  if (plain) *reinterpret_cast<u32x4*>(dst) = x;
+  else __builtin_nontemporal_store(x, reinterpret_cast<u32x4*>(dst));
+}
 __device__ __forceinline__ unsigned lds_addr(const void* p) {
   return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const unsigned char*)p;
 }
@@ -1323,6 +1328,7 @@ __global__ void __launch_bounds__(NTHR) k_local_attn_pw_bwd(LaParams p) {
   const int grp = qq / (ib * p.n_items), rem = qq - grp * (ib * p.n_items);
   const int b = (grp * ib + rem % ib) * 8 + xcd;
   if (b >= p.B_img) return;
+  GLR_STAMP2(0);
   const int tile0 = p.item_tile[rem / ib];
   const int D = p.D;
 
@@ -1412,13 +1418,16 @@ __global__ void __launch_bounds__(NTHR) k_local_attn_pw_bwd(LaParams p) {
   __syncthreads();
 
   // ================= P1 (both tiles, one stream of vt[b]) =================
+  GLR_STAMP2(1);
   f32x16 acc0[3], acc1[3];
 #pragma unroll
   for (int j = 0; j < 3; ++j)
 #pragma unroll
     for (int q = 0; q < 16; ++q) { acc0[j][q] = 0.f; acc1[j][q] = 0.f; }
+  if (!GLR_SKIP(1))
   stream_gemm<O, false, 2>(acc0, acc1, t * TW, 32 * CB, ring, (2 * TW + SP) * CB, p.tp + (size_t)tile0 * TW * rowbytes1,
                            rowbytes1, vt_b, rowbytes1, SP, (int)(rowbytes1 / CB), nullptr, 0, wave, lane, 0, wg, NRB, TW);
+  GLR_STAMP2(2);
 
   const int* fl = dsc + 32 + 8 * t;
   const unsigned ST0 = __builtin_amdgcn_readfirstlane(fl[0]), ST1 = __builtin_amdgcn_readfirstlane(fl[1]),
@@ -1438,7 +1447,7 @@ __global__ void __launch_bounds__(NTHR) k_local_attn_pw_bwd(LaParams p) {
   const float4* w4t = w4 + t * TW + 4 * h;
 
   // ================= P2 =================
-  {
+  if (!GLR_SKIP(4)) {
     float lc[3] = {0.f, 0.f, 0.f};
 #pragma unroll
     for (int blk = 0; blk < 2; ++blk) {
@@ -1476,32 +1485,26 @@ __global__ void __launch_bounds__(NTHR) k_local_attn_pw_bwd(LaParams p) {
     }
   }
   __syncthreads();                              // images complete; lt is dead: the P3 ring takes its place
-#if GLR_BWD_CUT == 1
-  { float u_ = 0.f; unsigned x_ = 0;
-_Pragma("unroll") for (int j = 0; j < 3; ++j) { _Pragma("unroll") for (int q = 0; q < 16; ++q) { u_ += acc0[j][q] * acc1[j][q]; x_ ^= a1k0[j][q >> 1] + a1k1[j][q >> 1] * (q + 1); } }
-    p.gamma[tid] = u_ + __uint_as_float(x_); return; }
-#endif
+  GLR_STAMP2(3);
 
   // ================= P3: acc += (beta a2) . G^T =================
+  if (!GLR_SKIP(8))
   stream_gemm<O, true, 2, 2>(acc0, acc1, 0, 32 * IMP, ring3, SP * CB, nullptr, 0, gram_b, rowbytes2, SP,
                             (int)(rowbytes2 / CB), img0 + t * IMG, IMP, wave, lane, 0, wg, NRB, TW);
+  GLR_STAMP2(4);
 
-#if GLR_BWD_CUT == 2
-  { float u_ = 0.f; unsigned x_ = 0;
-_Pragma("unroll") for (int j = 0; j < 3; ++j) { _Pragma("unroll") for (int q = 0; q < 16; ++q) { u_ += acc0[j][q] * acc1[j][q]; x_ ^= a1k0[j][q >> 1] + a1k1[j][q >> 1] * (q + 1); } }
-    p.gamma[tid] = u_ + __uint_as_float(x_); return; }
-#endif
-  if (p.baout != nullptr) {
+  if (p.baout != nullptr && !GLR_SKIP(128)) {
     // the operand image beta a2 itself is the third output
     for (int i = tid; i < 2 * TW * PPR; i += NTHR) {
       const int row = i / PPR, pc = i - row * PPR;
       const uint4 v = *reinterpret_cast<const uint4*>(img0 + (row >> 6) * IMG + (row & 63) * IMP + pc * 16);
-      *reinterpret_cast<uint4*>(p.baout + ((size_t)b * p.n_slots + (size_t)tile0 * TW + row) * (SP * ESZ) + pc * 16) = v;
+      st_stream16(p.baout + ((size_t)b * p.n_slots + (size_t)tile0 * TW + row) * (SP * ESZ) + pc * 16, v, GLR_SKIP(256));
     }
     __syncthreads();
   }
 
   // ================= A: da1, run sums of a1 da1, a2 image =================
+  GLR_STAMP2(5);
   const int nrow = long_pair ? 2 : NS;
   {
     float* tz = rh + h * HT + rbase;
@@ -1511,7 +1514,7 @@ _Pragma("unroll") for (int j = 0; j < 3; ++j) { _Pragma("unroll") for (int q = 0
       for (int j = 0; j < 3; ++j) tz[s2 * SP + 128 * j] = 0.f;
     }
   }
-  {
+  if (!GLR_SKIP(32)) {
     float rs[3] = {0.f, 0.f, 0.f};
 #pragma unroll
     for (int k = 0; k < 32; ++k) {
@@ -1545,15 +1548,12 @@ _Pragma("unroll") for (int j = 0; j < 3; ++j) { _Pragma("unroll") for (int q = 0
     }
   }
   __syncthreads();                              // a2 images and the run-sum tables (both tiles) are complete
-#if GLR_BWD_CUT == 3
-  { float u_ = 0.f; unsigned x_ = 0;
-_Pragma("unroll") for (int j = 0; j < 3; ++j) { _Pragma("unroll") for (int q = 0; q < 16; ++q) { u_ += acc0[j][q] * acc1[j][q]; x_ ^= a1k0[j][q >> 1] + a1k1[j][q >> 1] * (q + 1); } }
-    p.gamma[tid] = u_ + __uint_as_float(x_); return; }
-#endif
+  GLR_STAMP2(6);
+  if (!GLR_SKIP(128))
   for (int i = tid; i < 2 * TW * PPR; i += NTHR) {
     const int row = i / PPR, pc = i - row * PPR;
     const uint4 v = *reinterpret_cast<const uint4*>(img0 + (row >> 6) * IMG + (row & 63) * IMP + pc * 16);
-    *reinterpret_cast<uint4*>(p.aout + ((size_t)b * p.n_slots + (size_t)tile0 * TW + row) * (SP * ESZ) + pc * 16) = v;
+    st_stream16(p.aout + ((size_t)b * p.n_slots + (size_t)tile0 * TW + row) * (SP * ESZ) + pc * 16, v, GLR_SKIP(256));
   }
 
   // ================= B: X = acc - a1 rho (registers), then through the image to xout =================
@@ -1562,7 +1562,7 @@ _Pragma("unroll") for (int j = 0; j < 3; ++j) { _Pragma("unroll") for (int q = 0
   for (int j = 0; j < 3; ++j)
 #pragma unroll
     for (int i = 0; i < 8; ++i) { asm volatile("" : "+v"(a1k0[j][i])); asm volatile("" : "+v"(a1k1[j][i])); }
-  {
+  if (!GLR_SKIP(64)) {
     const float* r1 = (long_pair ? rh + SP : zero) + rbase;      // second row: the other tile's (spanning sentence) or zeros
     const int HT2 = long_pair ? HT : 0;
     float rc[3] = {0.f, 0.f, 0.f};
@@ -1593,6 +1593,7 @@ _Pragma("unroll") for (int j = 0; j < 3; ++j) { _Pragma("unroll") for (int q = 0
 #undef GLR_SBIT
 #undef GLR_SGK
   __syncthreads();                              // every thread has read its a2 rows out of the image
+  GLR_STAMP2(7);
 #pragma unroll
   for (int k = 0; k < 32; ++k) {
     const f32x16(&acc)[3] = k < 16 ? acc0 : acc1;
@@ -1602,11 +1603,14 @@ _Pragma("unroll") for (int j = 0; j < 3; ++j) { _Pragma("unroll") for (int q = 0
     for (int j = 0; j < 3; ++j) O::from_f32(imgw + row * IMP + 128 * j * ESZ, acc[j][q]);
   }
   __syncthreads();
+  GLR_STAMP2(8);
+  if (!GLR_SKIP(128))
   for (int i = tid; i < 2 * TW * PPR; i += NTHR) {
     const int row = i / PPR, pc = i - row * PPR;
     const uint4 v = *reinterpret_cast<const uint4*>(img0 + (row >> 6) * IMG + (row & 63) * IMP + pc * 16);
-    *reinterpret_cast<uint4*>(p.xout + (((size_t)tile0 * TW + row) * p.B_img + b) * (SP * ESZ) + pc * 16) = v;
+    st_stream16(p.xout + (((size_t)tile0 * TW + row) * p.B_img + b) * (SP * ESZ) + pc * 16, v, GLR_SKIP(256));
   }
+  GLR_STAMP2(9);
 }
 
 #ifdef GLR_STAMPS
@@ -1701,6 +1705,9 @@ int launch_pair_bwd(LaParams& p, int op_dtype, void* stream) {
   const int per_xcd = ((p.B_img + 7) / 8 + p.img_block - 1) / p.img_block * p.img_block;
   const int grid = per_xcd * 8 * p.n_items;
   if (p.pair_desc == nullptr || p.S_eff >= p.S_pad) return GLR_EINVAL;
+#ifdef GLR_ABLATE
+  { const char* e = getenv("GLR_K1_DBG"); p.dbg = e ? atoi(e) : 0; }
+#endif
   if (hipFuncSetAttribute((const void*)k_local_attn_pw_bwd<OpBF16>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return GLR_ELAUNCH;
   hipLaunchKernelGGL((k_local_attn_pw_bwd<OpBF16>), dim3(grid), dim3(NTHR), lds, (hipStream_t)stream, p);
   GLR_CHECK_LAUNCH();

@@ -24,58 +24,97 @@ extern "C" int glr_plan_tiles_bound(const int32_t* cap_lens, int n_sent, int cap
   return total;     // >= number of tiles and >= number of `order` entries
 }
 
-extern "C" int glr_plan_tiles(const int32_t* cap_lens, int n_sent, int capacity, int32_t* sent_slot0,
+extern "C" int glr_plan_tiles(const int32_t* cap_lens, int n_sent, int capacity, int max_pair_seg, int32_t* sent_slot0,
                               int32_t* tile_first, int32_t* order, int32_t* tile_nsub) {
   if (!cap_lens || !sent_slot0 || !tile_first || !order || !tile_nsub || n_sent <= 0) return GLR_EINVAL;
   if (capacity != 32 && capacity != GLR_TILE_WORDS) return GLR_EINVAL;
+  for (int i = 0; i < n_sent; ++i)
+    if (cap_lens[i] < 1 || cap_lens[i] > GLR_MAX_WORDS) return GLR_EINVAL;
   std::vector<int> fill;                       // used slots per tile (capacity = closed)
   std::vector<std::vector<int>> members;
   std::vector<int> nsub;
-  for (int i = 0; i < n_sent; ++i) {
-    const int n = cap_lens[i];
-    if (n < 1 || n > GLR_MAX_WORDS) return GLR_EINVAL;
-    if (n > capacity) {                        // multi-tile sentence: its own run of consecutive tiles
-      const int k = (n + capacity - 1) / capacity;
-      sent_slot0[i] = (int)fill.size() * GLR_TILE_WORDS;
-      for (int s = 0; s < k; ++s) {
-        fill.push_back(capacity);
-        members.emplace_back(1, i);
-        nsub.push_back(s == 0 ? k : -1);
+  // first fit in caption order, at most `max_sent` sentences per ordinary tile
+  auto pack = [&](int max_sent) {
+    fill.clear(); members.clear(); nsub.clear();
+    for (int i = 0; i < n_sent; ++i) {
+      const int n = cap_lens[i];
+      if (n > capacity) {                      // multi-tile sentence: its own run of consecutive tiles
+        const int k = (n + capacity - 1) / capacity;
+        for (int s = 0; s < k; ++s) {
+          fill.push_back(capacity);
+          members.emplace_back(1, i);
+          nsub.push_back(s == 0 ? k : -1);
+        }
+        continue;
       }
-      continue;
+      size_t t = 0;
+      while (t < fill.size() && (fill[t] + n > capacity || (int)members[t].size() >= max_sent)) ++t;
+      if (t == fill.size()) { fill.push_back(0); members.emplace_back(); nsub.push_back(0); }
+      fill[t] += n;
+      members[t].push_back(i);
     }
-    size_t t = 0;
-    while (t < fill.size() && fill[t] + n > capacity) ++t;   // first fit
-    if (t == fill.size()) { fill.push_back(0); members.emplace_back(); nsub.push_back(0); }
-    sent_slot0[i] = (int)t * GLR_TILE_WORDS + fill[t];
-    fill[t] += n;
-    members[t].push_back(i);
+  };
+  // work items the pair kernels would need for the current packing: ordinary tiles sorted by sentence count and
+  // paired fewest-with-most (the order built below), a pair holding at most max_pair_seg sentences
+  auto items = [&]() {
+    std::vector<int> cnt;
+    int n_items = 0;
+    for (size_t t = 0; t < members.size(); ++t) {
+      if (nsub[t] == 0) cnt.push_back((int)members[t].size());
+      else if (nsub[t] > 0) ++n_items;
+    }
+    std::sort(cnt.begin(), cnt.end());
+    std::vector<int> seq;
+    for (size_t lo = 0, hi = cnt.size(); lo < hi;) {
+      seq.push_back(cnt[lo++]);
+      if (lo < hi) seq.push_back(cnt[--hi]);
+    }
+    for (size_t t = 0; t < seq.size();) {
+      if (t + 1 < seq.size() && seq[t] + seq[t + 1] <= max_pair_seg) t += 2; else t += 1;
+      ++n_items;
+    }
+    return n_items;
+  };
+  // Plain first fit leaves the many short sentences of a length-sorted batch in the last tiles, which then hold more
+  // sentences than a pair may (max_pair_seg) and run as single tiles - a workgroup each, like a whole pair.  With
+  // pairing in view, a cap on the sentences per tile is chosen that minimises the number of work items (ties: fewer
+  // tiles): a tile more usually costs less than the pairs it unlocks.
+  int best_cap = n_sent;
+  if (max_pair_seg > 1 && capacity == GLR_TILE_WORDS) {
+    long best_cost = -1;
+    for (int cap = max_pair_seg; cap >= max_pair_seg / 2; --cap) {
+      pack(cap == max_pair_seg ? n_sent : cap);
+      const long cost = (long)items() * 4096 + (long)members.size();
+      if (best_cost < 0 || cost < best_cost) { best_cost = cost; best_cap = cap == max_pair_seg ? n_sent : cap; }
+    }
   }
-  // Tile ORDER is free (a tile is just 64 consecutive slots): the forward pairs consecutive ordinary tiles and a
-  // pair may hold at most 8 sentences, while first fit over length-sorted captions leaves the many short
-  // sentences in the last tiles.  Ordinary tiles are therefore re-ordered so that neighbours are balanced:
-  // fewest sentences next to most, second fewest next to second most, ...  (multi-tile sentences keep their runs).
+  pack(best_cap);
+  // Tile ORDER is free (a tile is just 64 consecutive slots): multi-tile sentences first (their runs stay
+  // together), then the ordinary tiles, contiguous - the pair kernels take two CONSECUTIVE ordinary tiles - and
+  // balanced: fewest sentences next to most, second fewest next to second most, ...
   {
-    std::vector<size_t> ord_idx;
-    for (size_t t = 0; t < members.size(); ++t) if (nsub[t] == 0) ord_idx.push_back(t);
-    std::vector<size_t> by_cnt(ord_idx);
+    std::vector<size_t> by_cnt, seq;
+    for (size_t t = 0; t < members.size(); ++t) if (nsub[t] != 0) seq.push_back(t);
+    for (size_t t = 0; t < members.size(); ++t) if (nsub[t] == 0) by_cnt.push_back(t);
     std::stable_sort(by_cnt.begin(), by_cnt.end(), [&](size_t a, size_t b) { return members[a].size() < members[b].size(); });
-    std::vector<size_t> seq;
     for (size_t lo = 0, hi = by_cnt.size(); lo < hi;) {
       seq.push_back(by_cnt[lo++]);
       if (lo < hi) seq.push_back(by_cnt[--hi]);
     }
-    std::vector<std::vector<int>> m2(members);
-    std::vector<int> f2(fill);
-    for (size_t i = 0; i < ord_idx.size(); ++i) { m2[ord_idx[i]] = members[seq[i]]; f2[ord_idx[i]] = fill[seq[i]]; }
+    std::vector<std::vector<int>> m2(members.size());
+    std::vector<int> f2(fill.size()), n2(nsub.size());
+    for (size_t i = 0; i < seq.size(); ++i) { m2[i] = members[seq[i]]; f2[i] = fill[seq[i]]; n2[i] = nsub[seq[i]]; }
     members.swap(m2);
     fill.swap(f2);
+    nsub.swap(n2);
     for (size_t t = 0; t < members.size(); ++t) {
       if (nsub[t] != 0) continue;
       int pos = 0;
       for (int s : members[t]) { sent_slot0[s] = (int)t * GLR_TILE_WORDS + pos; pos += cap_lens[s]; }
     }
   }
+  for (size_t t = 0; t < members.size(); ++t)
+    if (nsub[t] > 0) sent_slot0[members[t][0]] = (int)t * GLR_TILE_WORDS;
   int k = 0;
   for (size_t t = 0; t < members.size(); ++t) {
     tile_first[t] = k;

@@ -25,7 +25,7 @@ SYMBOLS = {
     "glr_region_pad": (c_int, [c_int]),
     "glr_tile_capacity": (c_int, [c_int]),
     "glr_plan_tiles_bound": (c_int, [c_void_p, c_int, c_int]),
-    "glr_plan_tiles": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "glr_plan_tiles": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "glr_plan_items": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "glr_plan_rowflags": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "glr_plan_pair_desc": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p]),
@@ -58,6 +58,11 @@ SYMBOLS = {
                                c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "glr_bn_act_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_longlong,
                                c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "glr_ln_workspace_floats": (c_int, [ctypes.c_longlong, c_int]),
+    "glr_drop_add_ln_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_longlong, c_int, c_float, c_float,
+                                    ctypes.c_ulonglong, ctypes.c_ulonglong, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "glr_drop_add_ln_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_longlong,
+                                    c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "glr_cell_counts": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "glr_kth_value": (c_int, [c_void_p, c_int, ctypes.c_longlong, ctypes.c_longlong, c_void_p, c_void_p]),
     "glr_topk_desc": (c_int, [c_void_p, c_int, ctypes.c_longlong, c_int, c_void_p, c_void_p, c_void_p]),
@@ -133,6 +138,9 @@ def require_cuda(*tensors):
             raise RuntimeError("the GLoRIA hot path runs on the GPU only (HIP kernels); got a CPU tensor")
 
 
+MAX_PAIR_SEG = 8        # sentences per tile pair (table rows of the pair kernels)
+
+
 class TilePlan:
     """Sentence -> word-slot packing (host planning by glr_plan_tiles + device copies)."""
 
@@ -147,7 +155,9 @@ class TilePlan:
         tile_first = np.zeros(bound + 1, dtype=np.int32)
         order = np.zeros(bound, dtype=np.int32)
         nsub = np.zeros(bound, dtype=np.int32)
-        nt = L.glr_plan_tiles(cl.ctypes.data_as(c_void_p), n, capacity, slot0.ctypes.data_as(c_void_p),
+        pairing = bool(allow_pairs and capacity == TILE_WORDS)
+        nt = L.glr_plan_tiles(cl.ctypes.data_as(c_void_p), n, capacity, MAX_PAIR_SEG if pairing else 0,
+                              slot0.ctypes.data_as(c_void_p),
                               tile_first.ctypes.data_as(c_void_p), order.ctypes.data_as(c_void_p),
                               nsub.ctypes.data_as(c_void_p))
         if nt <= 0:
@@ -157,7 +167,7 @@ class TilePlan:
         alls = np.zeros(nt, dtype=np.int32)
         counts = np.zeros(3, dtype=np.int32)
         rc = L.glr_plan_items(nsub.ctypes.data_as(c_void_p), tile_first.ctypes.data_as(c_void_p), nt,
-                              1 if (allow_pairs and capacity == TILE_WORDS) else 0, 8,
+                              1 if pairing else 0, MAX_PAIR_SEG,
                               singles.ctypes.data_as(c_void_p), pairs.ctypes.data_as(c_void_p),
                               alls.ctypes.data_as(c_void_p), counts.ctypes.data_as(c_void_p))
         if rc != 0:

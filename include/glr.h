@@ -68,6 +68,10 @@ int glr_tile_capacity(int op_dtype);
  *
  *   cap_lens[n_sent]    words per sentence (1..GLR_MAX_WORDS)
  *   capacity            glr_tile_capacity(op_dtype)
+ *   max_pair_seg        0: plain first fit.  > 1 (the value later given to glr_plan_items): tiles will be paired, a pair
+ *                       holding at most that many sentences - the planner then also caps the sentences per tile
+ *                       where that lowers the number of work items (a few more, emptier tiles instead of crowded
+ *                       tiles that cannot pair), and orders ordinary tiles fewest-sentences-next-to-most
  *   sent_slot0[n_sent]  out: global slot of the sentence's first word (tile * GLR_TILE_WORDS + pos);
  *                       word w of a multi-tile sentence sits at slot0 + (w / capacity) * GLR_TILE_WORDS
  *                       + w % capacity
@@ -79,7 +83,7 @@ int glr_tile_capacity(int op_dtype);
  * returns the number of tiles (>0) or a negative error.
  */
 int glr_plan_tiles_bound(const int32_t* cap_lens, int n_sent, int capacity);
-int glr_plan_tiles(const int32_t* cap_lens, int n_sent, int capacity, int32_t* sent_slot0,
+int glr_plan_tiles(const int32_t* cap_lens, int n_sent, int capacity, int max_pair_seg, int32_t* sent_slot0,
                    int32_t* tile_first, int32_t* order, int32_t* tile_nsub);
 
 /* Work items of the local-attention kernels.  With allow_pairs, two consecutive ordinary tiles that hold
@@ -348,6 +352,26 @@ int glr_bn_act_fwd(const void* x, const void* residual, const float* gamma, cons
 int glr_bn_act_bwd(const void* x, const void* dy, const void* y, const float* gamma, const float* beta, const float* mean,
                    const float* invstd, long long R, int C, int relu, int has_residual, float* workspace, float* out4c,
                    void* dx, void* dres, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Fused  y = LayerNorm(dropout(h) + inp)  of the BERT sub-layer outputs (reference: transformers'
+ * BertSelfOutput / BertOutput inside the BertModel of gloria/models/text_model.py:18-20, run under native AMP).
+ *   h16    bf16 [R, H]  output of the sub-layer's dense Linear        inp32  fp32 [R, H]  the residual stream
+ *   out32  fp32 [R, H]  y (the next residual stream)                  out16  bf16 [R, H]  y rounded (next GEMM operand)
+ *   stats  fp32 [R, 2]  mean, 1/std per row (for the backward)        mask   u64 [R, H/64] dropout keep bits: element
+ *                       4 (l + 64 i) + c of a row is bit l of word 4 i + c  (NULL when p_drop == 0)
+ *   seed / offset       Philox4x32-10 key / counter prefix: the mask is a pure function of (seed, offset, row, column)
+ * bwd: dy32 / dy16 = gradients w.r.t. out32 / out16 (either may be NULL); d_inp32 fp32, d_h16 bf16, dgamma / dbeta fp32 [H];
+ *      workspace: glr_ln_workspace_floats(R, H) floats (0 = shape not supported).  H in {256, 512, 768, 1024}.
+ * HBM-bound: 12 bytes per element forward, 18 backward; fixed-order reductions (bitwise reproducible).
+ */
+int glr_ln_workspace_floats(long long R, int H);
+int glr_drop_add_ln_fwd(const void* h16, const float* inp32, const float* gamma, const float* beta, long long R, int H,
+                        float eps, float p_drop, unsigned long long seed, unsigned long long offset, float* out32,
+                        void* out16, float* stats, unsigned long long* mask, void* stream);
+int glr_drop_add_ln_bwd(const float* dy32, const void* dy16, const void* h16, const float* inp32, const float* gamma,
+                        const float* stats, const unsigned long long* mask, long long R, int H, float p_drop,
+                        float* d_inp32, void* d_h16, float* workspace, float* dgamma, float* dbeta, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Image half of the collate function: replaces, for a ragged batch of single-channel images,

@@ -58,6 +58,17 @@ if not bwd:
         print(f"fwd PAIR kernel: workgroups {len(s2)}, median cycles per pair {np.median(t2):.0f}")
         for i, n in enumerate(n2):
             print(f"  {n:28s} median {np.median(d2[:, i]):9.0f}  share {np.median(d2[:, i]) / np.median(t2) * 100:5.1f}%")
+if bwd:
+    s2 = buf2.cpu().numpy().reshape(grid, 12)
+    s2 = s2[(s2[:, 0] > 0) & (s2[:, 9] > 0)]
+    if len(s2):
+        n2 = ["setup (descriptor, statistics, lse rows)", "P1 gemm (128 words)", "P2 (a1, a2, image, -alpha s)", "P3 gemm (128 words)",
+              "beta a2 copy out", "pass A (da1, run sums, a2 image)", "a2 copy out + pass B (X in registers)", "X -> image", "X copy out"]
+        d2 = np.diff(s2[:, :10].astype(np.float64), axis=1)
+        t2 = (s2[:, 9] - s2[:, 0]).astype(np.float64)
+        print(f"bwd PAIR kernel: workgroups {len(s2)}, median ticks per pair {np.median(t2):.0f}")
+        for i, n in enumerate(n2):
+            print(f"  {n:40s} median {np.median(d2[:, i]):9.0f}  share {np.median(d2[:, i]) / np.median(t2) * 100:5.1f}%")
 st = buf.cpu().numpy().reshape(grid, 12)
 st = st[st[:, 0] > 0]
 if bwd:
