@@ -8,6 +8,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .fused_ln import drop_add_ln
+
 
 class BertConfig:
     def __init__(self, vocab_size=28996, hidden_size=768, num_hidden_layers=12, num_attention_heads=12,
@@ -66,7 +68,8 @@ class BertSelfOutput(nn.Module):
         self.dropout = nn.Dropout(c.hidden_dropout_prob)
 
     def forward(self, h, inp):
-        return self.LayerNorm(self.dropout(self.dense(h)) + inp)
+        # (y fp32, y bf16 | None): dropout + residual + LayerNorm in one HIP pass under bf16 autocast (models/fused_ln.py)
+        return drop_add_ln(self.dense(h), inp, self.LayerNorm, self.dropout.p, self.training)
 
 
 class BertAttention(nn.Module):
@@ -75,8 +78,9 @@ class BertAttention(nn.Module):
         self.self = BertSelfAttention(c)
         self.output = BertSelfOutput(c)
 
-    def forward(self, x, bias):
-        return self.output(self.self(x, bias), x)
+    def forward(self, x, bias, x16=None):
+        # x16: the bf16 copy of x the fused sub-layer epilogue already wrote (the operand autocast would cast x to)
+        return self.output(self.self(x if x16 is None else x16, bias), x)
 
 
 class BertIntermediate(nn.Module):
@@ -96,7 +100,7 @@ class BertOutput(nn.Module):
         self.dropout = nn.Dropout(c.hidden_dropout_prob)
 
     def forward(self, h, inp):
-        return self.LayerNorm(self.dropout(self.dense(h)) + inp)
+        return drop_add_ln(self.dense(h), inp, self.LayerNorm, self.dropout.p, self.training)
 
 
 class BertLayer(nn.Module):
@@ -106,9 +110,10 @@ class BertLayer(nn.Module):
         self.intermediate = BertIntermediate(c)
         self.output = BertOutput(c)
 
-    def forward(self, x, bias):
-        a = self.attention(x, bias)
-        return self.output(self.intermediate(a), a)
+    def forward(self, x, bias, x16=None):
+        """(hidden state fp32, its bf16 copy or None)"""
+        a, a16 = self.attention(x, bias, x16)
+        return self.output(self.intermediate(a if a16 is None else a16), a)
 
 
 class BertEncoderStack(nn.Module):
@@ -158,7 +163,8 @@ class BertModel(nn.Module):
         if attention_mask is not None:          # boolean key mask (True = attend), broadcast over heads/queries
             bias = (attention_mask != 0)[:, None, None, :]
         hidden = [x]
+        x16 = None
         for layer in self.encoder.layer:
-            x = layer(x, bias)
+            x, x16 = layer(x, bias, x16)
             hidden.append(x)
         return x, self.pooler(x), tuple(hidden)

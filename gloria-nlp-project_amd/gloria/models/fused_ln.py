@@ -1,0 +1,99 @@
+"""y = LayerNorm(dropout(h) + inp) of the BERT sub-layer outputs as ONE HBM pass per direction
+(include/glr.h: glr_drop_add_ln_fwd / _bwd; reference: transformers' BertSelfOutput / BertOutput inside the BertModel
+of /root/reference/gloria/models/text_model.py:18-20 under native AMP).
+
+`drop_add_ln(h, inp, ln, p, training)` returns (y fp32, y bf16 or None).  The kernels cover what the training step
+runs: GPU, bf16 autocast (h bf16 from the dense Linear, fp32 residual stream, fp32 LayerNorm parameters), hidden sizes
+256 / 512 / 768 / 1024.  Every other case (fp32 parity mode, CPU tensors of the host-logic tests) is torch's own
+dropout + add + layer_norm - the same operators from the library - and returns (y, None).  The second output is y
+rounded to bf16, the operand of the next Linear (autocast would make that copy itself, in a pass of its own).
+Dropout bits: Philox4x32-10 keyed by the CUDA generator's seed and offset (the offset is advanced), so runs are
+reproducible under torch.manual_seed and resume with a restored RNG state; not the same stream as torch's own dropout.
+`GLR_FUSED_LN=0` switches the kernels off (A/B measurements)."""
+
+import os
+
+import torch
+import torch.nn.functional as F
+
+from .. import _native as N
+
+ENABLED = os.environ.get("GLR_FUSED_LN", "1") != "0"
+_WS = {}
+
+
+def _workspace(dev, n):
+    ws = _WS.get(dev.index)
+    if ws is None or ws.numel() < n:
+        ws = torch.empty(max(n, 1 << 21), dtype=torch.float32, device=dev)
+        _WS[dev.index] = ws
+    return ws
+
+
+def _philox_args(dev):
+    gen = torch.cuda.default_generators[dev.index if dev.index is not None else torch.cuda.current_device()]
+    seed, off = gen.initial_seed(), gen.get_offset()
+    gen.set_offset(off + 4)
+    return seed & 0xFFFFFFFFFFFFFFFF, off
+
+
+class _DropAddLN(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, h, inp, weight, bias, eps, p):
+        L = N.lib()
+        H = h.shape[-1]
+        R = h.numel() // H
+        dev = h.device
+        out32 = torch.empty(h.shape, dtype=torch.float32, device=dev)
+        out16 = torch.empty(h.shape, dtype=torch.bfloat16, device=dev)
+        stats = torch.empty(R, 2, dtype=torch.float32, device=dev)
+        mask = torch.empty(R, H // 64, dtype=torch.int64, device=dev) if p > 0 else None
+        seed, off = _philox_args(dev) if p > 0 else (0, 0)
+        N.check(L.glr_drop_add_ln_fwd(N.ptr(h), N.ptr(inp), N.ptr(weight), N.ptr(bias), R, H, float(eps), float(p), seed, off,
+                                      N.ptr(out32), N.ptr(out16), N.ptr(stats), N.ptr(mask), N.stream()), "glr_drop_add_ln_fwd")
+        ctx.save_for_backward(h, inp, weight, stats, mask)
+        ctx.p = float(p)
+        ctx.set_materialize_grads(False)
+        return out32, out16
+
+    @staticmethod
+    def backward(ctx, d32, d16):
+        h, inp, weight, stats, mask = ctx.saved_tensors
+        L = N.lib()
+        H = h.shape[-1]
+        R = h.numel() // H
+        dev = h.device
+        if d32 is None and d16 is None:
+            return None, None, None, None, None, None
+        if d32 is not None:
+            d32 = d32.float().contiguous()
+        if d16 is not None:
+            d16 = d16.to(torch.bfloat16).contiguous()
+        d_inp = torch.empty(h.shape, dtype=torch.float32, device=dev)
+        d_h = torch.empty(h.shape, dtype=torch.bfloat16, device=dev)
+        dgb = torch.empty(2, H, dtype=torch.float32, device=dev)
+        ws = _workspace(dev, L.glr_ln_workspace_floats(R, H))
+        N.check(L.glr_drop_add_ln_bwd(N.ptr(d32), N.ptr(d16), N.ptr(h), N.ptr(inp), N.ptr(weight), N.ptr(stats), N.ptr(mask), R, H,
+                                      ctx.p, N.ptr(d_inp), N.ptr(d_h), N.ptr(ws), N.ptr(dgb), c_off(dgb, H), N.stream()),
+                "glr_drop_add_ln_bwd")
+        return d_h, d_inp, dgb[0], dgb[1], None, None
+
+
+def c_off(t, n_elems):
+    """pointer to element n_elems of a contiguous fp32 tensor"""
+    return N.c_void_p(t.data_ptr() + 4 * n_elems)
+
+
+def _fusable(h, inp, ln):
+    H = h.shape[-1]
+    return (ENABLED and h.is_cuda and h.dtype == torch.bfloat16 and inp.dtype == torch.float32 and h.shape == inp.shape
+            and H % 256 == 0 and 256 <= H <= 1024 and ln.elementwise_affine and ln.weight.dtype == torch.float32
+            and ln.bias is not None and ln.bias.dtype == torch.float32 and tuple(ln.normalized_shape) == (H,)
+            and h.is_contiguous() and inp.is_contiguous())
+
+
+def drop_add_ln(h, inp, ln, p, training):
+    """(LayerNorm(dropout(h) + inp) in fp32, the same rounded to bf16 or None)."""
+    if _fusable(h, inp, ln):
+        return _DropAddLN.apply(h, inp, ln.weight, ln.bias, ln.eps, p if training else 0.0)
+    return ln(F.dropout(h, p, training) + inp), None
