@@ -8,6 +8,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .fused_attn import self_attention
 from .fused_ln import drop_add_ln
 
 
@@ -52,12 +53,11 @@ class BertSelfAttention(nn.Module):
         self.p = c.attention_probs_dropout_prob
 
     def forward(self, x, bias):
+        # bias: bool key mask [B, 1, 1, L] (True = attend) or None.  softmax(QK^T) -> dropout -> .V on the Linear outputs
+        # as they are: one HIP kernel per direction for short captions under bf16 autocast (models/fused_attn.py)
         B, L, H = x.shape
-        q = self.query(x).view(B, L, self.nh, self.hd).transpose(1, 2)
-        k = self.key(x).view(B, L, self.nh, self.hd).transpose(1, 2)
-        v = self.value(x).view(B, L, self.nh, self.hd).transpose(1, 2)
-        o = F.scaled_dot_product_attention(q, k, v, attn_mask=bias, dropout_p=self.p if self.training else 0.0)
-        return o.transpose(1, 2).reshape(B, L, H)
+        key_mask = None if bias is None else bias.reshape(B, L)
+        return self_attention(self.query(x), self.key(x), self.value(x), key_mask, self.nh, self.p, self.training)
 
 
 class BertSelfOutput(nn.Module):

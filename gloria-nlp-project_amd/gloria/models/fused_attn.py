@@ -1,0 +1,76 @@
+"""BertSelfAttention's softmax(Q K^T / sqrt(d) + mask) -> dropout -> . V for short captions as ONE HIP kernel per direction
+(include/glr.h: glr_attn_fwd / glr_attn_bwd; reference: transformers' BertSelfAttention inside the BertModel of
+/root/reference/gloria/models/text_model.py:18-20).
+
+`self_attention(q, k, v, key_mask, n_heads, p, training)` takes the [B, L, H] outputs of the query / key / value Linears
+as they are and returns the context in the same layout.  The kernels cover what the training step runs: GPU, bf16
+(autocast), head size 64, L <= 112 tokens; every other case is torch's scaled_dot_product_attention on the same
+tensors.  Dropout bits: Philox4x32-10 keyed by the CUDA generator's seed and offset (reproducible under
+torch.manual_seed; not the same stream as torch's own dropout).  `GLR_FUSED_ATTN=0` switches the kernels off."""
+
+import math
+import os
+
+import torch
+import torch.nn.functional as F
+
+from .. import _native as N
+from .fused_ln import _philox_args
+
+ENABLED = os.environ.get("GLR_FUSED_ATTN", "1") != "0"
+_MAX_L = None
+
+
+def _max_tokens():
+    global _MAX_L
+    if _MAX_L is None:
+        _MAX_L = int(N.lib().glr_attn_max_tokens(1))
+    return _MAX_L
+
+
+class _SelfAttn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, k, v, key_mask, nh, p, scale):
+        L_ = N.lib()
+        B, L, H = q.shape
+        dev = q.device
+        o = torch.empty_like(q)
+        lse = torch.empty(B * nh, 128, dtype=torch.float32, device=dev)
+        keep = torch.empty(B * nh, 128, 4, dtype=torch.int32, device=dev) if p > 0 else None
+        seed, off = _philox_args(dev) if p > 0 else (0, 0)
+        N.check(L_.glr_attn_fwd(N.ptr(q), N.ptr(k), N.ptr(v), N.ptr(key_mask), B, nh, L, H, float(scale), float(p), seed, off,
+                                N.ptr(o), N.ptr(lse), N.ptr(keep), N.stream()), "glr_attn_fwd")
+        ctx.save_for_backward(q, k, v, o, lse, keep, key_mask)
+        ctx.meta = (nh, float(p), float(scale))
+        return o
+
+    @staticmethod
+    def backward(ctx, d_o):
+        q, k, v, o, lse, keep, key_mask = ctx.saved_tensors
+        nh, p, scale = ctx.meta
+        L_ = N.lib()
+        B, L, H = q.shape
+        d_o = d_o.to(torch.bfloat16).contiguous()
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(q), torch.empty_like(q)
+        N.check(L_.glr_attn_bwd(N.ptr(q), N.ptr(k), N.ptr(v), N.ptr(o), N.ptr(d_o), N.ptr(key_mask), N.ptr(lse), N.ptr(keep),
+                                B, nh, L, H, scale, p, N.ptr(dq), N.ptr(dk), N.ptr(dv), N.stream()), "glr_attn_bwd")
+        return dq, dk, dv, None, None, None, None
+
+
+def _fusable(q, k, v, key_mask, nh):
+    B, L, H = q.shape
+    return (ENABLED and q.is_cuda and q.dtype == k.dtype == v.dtype == torch.bfloat16 and H == nh * 64 and L <= _max_tokens()
+            and q.is_contiguous() and k.is_contiguous() and v.is_contiguous()
+            and (key_mask is None or (key_mask.dtype == torch.bool and tuple(key_mask.shape) == (B, L) and key_mask.is_contiguous())))
+
+
+def self_attention(q, k, v, key_mask, nh, p, training):
+    """q, k, v: [B, L, H]; key_mask: bool [B, L] (True = attend) or None -> context [B, L, H]."""
+    B, L, H = q.shape
+    hd = H // nh
+    if _fusable(q, k, v, key_mask, nh):
+        return _SelfAttn.apply(q, k, v, key_mask, nh, p if training else 0.0, 1.0 / math.sqrt(hd))
+    bias = None if key_mask is None else key_mask[:, None, None, :]
+    qh, kh, vh = (t.view(B, L, nh, hd).transpose(1, 2) for t in (q, k, v))
+    o = F.scaled_dot_product_attention(qh, kh, vh, attn_mask=bias, dropout_p=p if training else 0.0)
+    return o.transpose(1, 2).reshape(B, L, H)

@@ -374,6 +374,25 @@ int glr_drop_add_ln_bwd(const float* dy32, const void* dy16, const void* h16, co
                         float* d_inp32, void* d_h16, float* workspace, float* dgamma, float* dbeta, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Self-attention of the BERT text encoder for short captions (reference: BertSelfAttention of
+ * transformers' BertModel, gloria/models/text_model.py:18-20; 97 tokens in imagenome_pretrain_config.yaml):
+ *   O = dropout(softmax(Q K^T * scale + key mask)) V      per (sentence, head), head size 64, L <= 128 tokens.
+ * q, k, v, o, d_o, dq, dk, dv: bf16 [B, L, ld] with head h in columns [64 h, 64 h + 64) (the Linear outputs read in
+ * place, ld = hidden size); key_mask uint8 [B, L] (nonzero = attend) or NULL; lse fp32 [B * n_heads, 128] (row
+ * log-sum-exp, saved for the backward); keep uint32 [B * n_heads, 128, 4]: dropout keep bits, key 32 j + i of query
+ * row r = bit i of word (r, j) (NULL when p_drop == 0).  seed / offset: Philox4x32-10 key / counter prefix.
+ * One workgroup per (sentence, head); glr_attn_max_tokens(backward) = largest L whose operands fit the 160 KB LDS
+ * (128 forward, 112 backward).  Replaces a library flash-attention call that spends 95 + 390 us per layer here.
+ */
+int glr_attn_max_tokens(int backward);
+int glr_attn_fwd(const void* q, const void* k, const void* v, const uint8_t* key_mask, int B, int n_heads, int L, int ld,
+                 float scale, float p_drop, unsigned long long seed, unsigned long long offset, void* o, float* lse,
+                 uint32_t* keep, void* stream);
+int glr_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o, const uint8_t* key_mask,
+                 const float* lse, const uint32_t* keep, int B, int n_heads, int L, int ld, float scale, float p_drop,
+                 void* dq, void* dk, void* dv, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Image half of the collate function: replaces, for a ragged batch of single-channel images,
  *   original_tensor_to_numpy_image   gloria/datasets/mimic_for_gloria.py:36-42  (min-max -> uint8, truncating)
  *   GloriaCollateFn._resize_img      mimic_for_gloria.py:136-181   (cv2.INTER_AREA long side -> scale, zero pad)

@@ -220,7 +220,7 @@ def test_flat_optimizer_step_equals_stock_amp_step_and_resumes(tmp_path):
     # step 1 differs only by rounding paths; later steps carry Adam updates whose sign-like normalisation amplifies
     # bf16-level gradient differences (the same band as the data-parallel rehearsal above)
     np.testing.assert_allclose(losses[True][0], losses[False][0], rtol=1e-3)
-    np.testing.assert_allclose(losses[True], losses[False], rtol=2e-2)
+    np.testing.assert_allclose(losses[True], losses[False], rtol=4e-2)
     tr, model = trainers[True], models[True]
     w = model.gloria.text_encoder.model.encoder.layer[0].attention.self.query.weight
     assert w.dtype == torch.bfloat16
