@@ -31,7 +31,7 @@ constexpr float AT_LOG2E = 1.4426950408889634f;
 struct AttnParams {
   const unsigned short* q; const unsigned short* k; const unsigned short* v;   // [B, L, ld]
   const unsigned char* key_mask;    // [B, L] nonzero = attend; NULL = all
-  int B, nh, L, ld;
+  int B, nh, L, ld, ld_o;           // row strides (elements) of q / k / v / dq / dk / dv and of o / d_o
   float scale, p_drop;
   unsigned seed_lo, seed_hi, off_lo, off_hi;
   unsigned short* o;                // fwd out / bwd in
@@ -241,7 +241,7 @@ __global__ void __launch_bounds__(AT_NT) k_attn_fwd(AttnParams p) {
   f32x16 out[2];
   zero16(out[0]); zero16(out[1]);
   gemm_tokens(out, slab, Vt, tp, kt, l31, h);
-  store_rows(out, slab, tp, p.o + base, p.ld, row0, L, lane, l31, h);
+  store_rows(out, slab, tp, p.o + (size_t)b * L * p.ld_o + (size_t)hd * 64, p.ld_o, row0, L, lane, l31, h);
 }
 
 __global__ void __launch_bounds__(AT_NT) k_attn_bwd(AttnParams p) {
@@ -268,8 +268,8 @@ __global__ void __launch_bounds__(AT_NT) k_attn_bwd(AttnParams p) {
     tile_load(p.q + base, p.ld, L, rq, tid);
     tile_load(p.k + base, p.ld, L, rk, tid);
     tile_load(p.v + base, p.ld, L, rv, tid);
-    tile_load(p.d_o + base, p.ld, L, rg, tid);
-    tile_load(p.o + base, p.ld, L, ro, tid);
+    tile_load(p.d_o + (size_t)b * L * p.ld_o + (size_t)hd * 64, p.ld_o, L, rg, tid);
+    tile_load(p.o + (size_t)b * L * p.ld_o + (size_t)hd * 64, p.ld_o, L, ro, tid);
     if (tid < 128) {
       kb[tid] = (tid < L && (p.key_mask == nullptr || p.key_mask[(size_t)b * L + tid] != 0)) ? 0.f : -INFINITY;
       lse[tid] = tid < L ? p.lse[(size_t)bh * 128 + tid] * AT_LOG2E : 0.f;
@@ -373,11 +373,12 @@ size_t attn_lds_fwd(int L) { return (size_t)2 * 128 * AT_RP + (size_t)64 * attn_
 size_t attn_lds_bwd(int L) { return (size_t)4 * 128 * AT_RP + (size_t)3 * 64 * attn_tp(L) + (size_t)128 * AT_SP + 4 * 512 + 2048; }
 
 int attn_fill(AttnParams& p, const void* q, const void* k, const void* v, const unsigned char* key_mask, int B, int nh, int L, int ld,
-              float scale, float p_drop, unsigned long long seed, unsigned long long offset) {
-  if (!q || !k || !v || B <= 0 || nh <= 0 || L <= 0 || L > 128 || ld < nh * 64 || ld % 8 != 0) return GLR_EINVAL;
+              int ld_o, float scale, float p_drop, unsigned long long seed, unsigned long long offset) {
+  if (!q || !k || !v || B <= 0 || nh <= 0 || L <= 0 || L > 128 || ld < nh * 64 || ld % 8 != 0 || ld_o < nh * 64 || ld_o % 8 != 0)
+    return GLR_EINVAL;
   if (p_drop < 0.f || p_drop >= 1.f) return GLR_EINVAL;
   p.q = (const unsigned short*)q; p.k = (const unsigned short*)k; p.v = (const unsigned short*)v; p.key_mask = key_mask;
-  p.B = B; p.nh = nh; p.L = L; p.ld = ld; p.scale = scale; p.p_drop = p_drop;
+  p.B = B; p.nh = nh; p.L = L; p.ld = ld; p.ld_o = ld_o; p.scale = scale; p.p_drop = p_drop;
   p.seed_lo = (unsigned)seed; p.seed_hi = (unsigned)(seed >> 32); p.off_lo = (unsigned)offset; p.off_hi = (unsigned)(offset >> 32);
   p.o = nullptr; p.lse = nullptr; p.keep = nullptr; p.d_o = nullptr; p.dq = p.dk = p.dv = nullptr;
   p.tp = attn_tp(L);
@@ -393,10 +394,10 @@ extern "C" int glr_attn_max_tokens(int backward) {
 }
 
 extern "C" int glr_attn_fwd(const void* q, const void* k, const void* v, const uint8_t* key_mask, int B, int n_heads, int L, int ld,
-                            float scale, float p_drop, unsigned long long seed, unsigned long long offset, void* o, float* lse,
+                            int ld_o, float scale, float p_drop, unsigned long long seed, unsigned long long offset, void* o, float* lse,
                             uint32_t* keep, void* stream) {
   AttnParams p;
-  const int rc = attn_fill(p, q, k, v, key_mask, B, n_heads, L, ld, scale, p_drop, seed, offset);
+  const int rc = attn_fill(p, q, k, v, key_mask, B, n_heads, L, ld, ld_o, scale, p_drop, seed, offset);
   if (rc != GLR_OK) return rc;
   if (!o || !lse || (p_drop > 0.f && !keep) || L > glr_attn_max_tokens(0)) return GLR_EINVAL;
   p.o = (unsigned short*)o; p.lse = lse; p.keep = keep;
@@ -408,10 +409,10 @@ extern "C" int glr_attn_fwd(const void* q, const void* k, const void* v, const u
 }
 
 extern "C" int glr_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o, const uint8_t* key_mask,
-                            const float* lse, const uint32_t* keep, int B, int n_heads, int L, int ld, float scale, float p_drop,
+                            const float* lse, const uint32_t* keep, int B, int n_heads, int L, int ld, int ld_o, float scale, float p_drop,
                             void* dq, void* dk, void* dv, void* stream) {
   AttnParams p;
-  const int rc = attn_fill(p, q, k, v, key_mask, B, n_heads, L, ld, scale, p_drop, 0, 0);
+  const int rc = attn_fill(p, q, k, v, key_mask, B, n_heads, L, ld, ld_o, scale, p_drop, 0, 0);
   if (rc != GLR_OK) return rc;
   if (!o || !d_o || !lse || !dq || !dk || !dv || (p_drop > 0.f && !keep) || L > glr_attn_max_tokens(1)) return GLR_EINVAL;
   p.o = (unsigned short*)const_cast<void*>(o); p.d_o = (const unsigned short*)d_o; p.lse = const_cast<float*>(lse);

@@ -135,8 +135,9 @@ __device__ __forceinline__ double wave_sum(double v) {
 template <bool FWD>
 __global__ void __launch_bounds__(BN_NT) k_bn_finish(const float* __restrict__ part, int n_part, int C, long long R, float eps,
                                                      float momentum, float* __restrict__ o0, float* __restrict__ o1,
-                                                     float* __restrict__ o2, float* __restrict__ o3) {
+                                                     float* __restrict__ o2, float* __restrict__ o3, long long* __restrict__ counter) {
   const int lane = threadIdx.x & 63;
+  if (counter != nullptr && blockIdx.x == 0 && threadIdx.x == 0) counter[0] += 1;     // nn.BatchNorm2d.num_batches_tracked
   const int c = blockIdx.x * (BN_NT / 64) + (threadIdx.x >> 6);
   if (c >= C) return;
   const float* p0 = part + (size_t)c * n_part;
@@ -297,8 +298,9 @@ extern "C" int glr_bn_workspace_floats(long long R, int C) {
 }
 
 extern "C" int glr_bn_act_fwd(const void* x, const void* residual, const float* gamma, const float* beta, long long R,
-                              int C, float eps, float momentum, int relu, float* run_mean, float* run_var, float* mean,
-                              float* invstd, float* workspace, void* y, void* stream) {
+                              int C, float eps, float momentum, int relu, float* run_mean, float* run_var,
+                              long long* num_batches_tracked, float* mean, float* invstd, float* workspace, void* y,
+                              void* stream) {
   if (!x || !gamma || !beta || !mean || !invstd || !workspace || !y || !bn_shape_ok(R, C)) return GLR_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   static const int res0 = bn_resident((const void*)k_bn_reduce<0, false>);
@@ -307,7 +309,7 @@ extern "C" int glr_bn_act_fwd(const void* x, const void* residual, const float* 
                      nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, R, C, 0, pl.n_part, workspace, nullptr);
   GLR_CHECK_LAUNCH();
   hipLaunchKernelGGL((k_bn_finish<true>), dim3((C + 3) / 4), dim3(BN_NT), 0, st, workspace, pl.n_part, C, R, eps, momentum,
-                     mean, invstd, run_mean, run_var);
+                     mean, invstd, run_mean, run_var, num_batches_tracked);
   GLR_CHECK_LAUNCH();
   const long long n_vec = R * C / 8;
   const int grid = (int)((n_vec + BN_NT * 4 - 1) / (BN_NT * 4));
@@ -343,7 +345,7 @@ extern "C" int glr_bn_act_bwd(const void* x, const void* dy, const void* y, cons
                        nullptr, mean, invstd, gamma, beta, R, C, relu, pl.n_part, workspace, nullptr);
   GLR_CHECK_LAUNCH();
   hipLaunchKernelGGL((k_bn_finish<false>), dim3((C + 3) / 4), dim3(BN_NT), 0, st, workspace, pl.n_part, C, R, 0.f, 0.f, out4c,
-                     out4c + C, out4c + 2 * C, out4c + 3 * C);
+                     out4c + C, out4c + 2 * C, out4c + 3 * C, (long long*)nullptr);
   GLR_CHECK_LAUNCH();
   const long long n_vec = R * C / 8;
   const int grid = (int)((n_vec + BN_NT * 4 - 1) / (BN_NT * 4));

@@ -55,7 +55,7 @@ SYMBOLS = {
                               c_float, c_float, c_float, c_float, c_int, c_void_p, c_void_p]),
     "glr_bn_workspace_floats": (c_int, [ctypes.c_longlong, c_int]),
     "glr_bn_act_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_longlong, c_int, c_float, c_float, c_int,
-                               c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+                               c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "glr_bn_act_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_longlong,
                                c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "glr_ln_workspace_floats": (c_int, [ctypes.c_longlong, c_int]),
@@ -64,10 +64,10 @@ SYMBOLS = {
     "glr_drop_add_ln_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_longlong,
                                     c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "glr_attn_max_tokens": (c_int, [c_int]),
-    "glr_attn_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_float,
+    "glr_attn_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_float,
                              ctypes.c_ulonglong, ctypes.c_ulonglong, c_void_p, c_void_p, c_void_p, c_void_p]),
     "glr_attn_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
-                             c_int, c_int, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
+                             c_int, c_int, c_int, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
     "glr_cell_counts": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "glr_kth_value": (c_int, [c_void_p, c_int, ctypes.c_longlong, ctypes.c_longlong, c_void_p, c_void_p]),
     "glr_topk_desc": (c_int, [c_void_p, c_int, ctypes.c_longlong, c_int, c_void_p, c_void_p, c_void_p]),
@@ -130,7 +130,8 @@ def torch_dtype(code):
 
 
 def ptr(t):
-    return None if t is None else c_void_p(t.data_ptr())
+    """device address of a tensor as a plain int (ctypes converts it for a c_void_p parameter) or None"""
+    return None if t is None else t.data_ptr()
 
 
 def stream():

@@ -8,7 +8,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .fused_attn import self_attention
+from .fused_attn import packed_fusable, self_attention, self_attention_packed
 from .fused_ln import drop_add_ln
 
 
@@ -57,6 +57,12 @@ class BertSelfAttention(nn.Module):
         # as they are: one HIP kernel per direction for short captions under bf16 autocast (models/fused_attn.py)
         B, L, H = x.shape
         key_mask = None if bias is None else bias.reshape(B, L)
+        if packed_fusable(x, self.nh, H, L, key_mask):
+            # one [H -> 3H] GEMM instead of three [H -> H] ones (at 25k tokens x 768 the library runs the small ones at
+            # under 200 TFLOP/s), and the kernels read / write the packed tensor in place: no split, no gradient adds
+            w = torch.cat([self.query.weight, self.key.weight, self.value.weight], 0)
+            b_ = torch.cat([self.query.bias, self.key.bias, self.value.bias], 0)
+            return self_attention_packed(F.linear(x, w, b_), key_mask, self.nh, self.p, self.training)
         return self_attention(self.query(x), self.key(x), self.value(x), key_mask, self.nh, self.p, self.training)
 
 

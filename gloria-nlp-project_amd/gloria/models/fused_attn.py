@@ -38,7 +38,7 @@ class _SelfAttn(torch.autograd.Function):
         lse = torch.empty(B * nh, 128, dtype=torch.float32, device=dev)
         keep = torch.empty(B * nh, 128, 4, dtype=torch.int32, device=dev) if p > 0 else None
         seed, off = _philox_args(dev) if p > 0 else (0, 0)
-        N.check(L_.glr_attn_fwd(N.ptr(q), N.ptr(k), N.ptr(v), N.ptr(key_mask), B, nh, L, H, float(scale), float(p), seed, off,
+        N.check(L_.glr_attn_fwd(N.ptr(q), N.ptr(k), N.ptr(v), N.ptr(key_mask), B, nh, L, H, H, float(scale), float(p), seed, off,
                                 N.ptr(o), N.ptr(lse), N.ptr(keep), N.stream()), "glr_attn_fwd")
         ctx.save_for_backward(q, k, v, o, lse, keep, key_mask)
         ctx.meta = (nh, float(p), float(scale))
@@ -53,8 +53,46 @@ class _SelfAttn(torch.autograd.Function):
         d_o = d_o.to(torch.bfloat16).contiguous()
         dq, dk, dv = torch.empty_like(q), torch.empty_like(q), torch.empty_like(q)
         N.check(L_.glr_attn_bwd(N.ptr(q), N.ptr(k), N.ptr(v), N.ptr(o), N.ptr(d_o), N.ptr(key_mask), N.ptr(lse), N.ptr(keep),
-                                B, nh, L, H, scale, p, N.ptr(dq), N.ptr(dk), N.ptr(dv), N.stream()), "glr_attn_bwd")
+                                B, nh, L, H, H, scale, p, N.ptr(dq), N.ptr(dk), N.ptr(dv), N.stream()), "glr_attn_bwd")
         return dq, dk, dv, None, None, None, None
+
+
+class _SelfAttnPacked(torch.autograd.Function):
+    """the same kernels on ONE [B, L, 3H] tensor (query | key | value columns): the output of a single fused Linear.
+    The backward writes dq | dk | dv straight into the gradient of that tensor (row stride 3H on both sides)."""
+
+    @staticmethod
+    def forward(ctx, qkv, key_mask, nh, p, scale):
+        L_ = N.lib()
+        B, L, H3 = qkv.shape
+        H = H3 // 3
+        dev = qkv.device
+        o = torch.empty(B, L, H, dtype=qkv.dtype, device=dev)
+        lse = torch.empty(B * nh, 128, dtype=torch.float32, device=dev)
+        keep = torch.empty(B * nh, 128, 4, dtype=torch.int32, device=dev) if p > 0 else None
+        seed, off = _philox_args(dev) if p > 0 else (0, 0)
+        base = qkv.data_ptr()
+        N.check(L_.glr_attn_fwd(N.c_void_p(base), N.c_void_p(base + 2 * H), N.c_void_p(base + 4 * H), N.ptr(key_mask), B, nh, L, H3, H,
+                                float(scale), float(p), seed, off, N.ptr(o), N.ptr(lse), N.ptr(keep), N.stream()),
+                "glr_attn_fwd")
+        ctx.save_for_backward(qkv, o, lse, keep, key_mask)
+        ctx.meta = (nh, float(p), float(scale))
+        return o
+
+    @staticmethod
+    def backward(ctx, d_o):
+        qkv, o, lse, keep, key_mask = ctx.saved_tensors
+        nh, p, scale = ctx.meta
+        L_ = N.lib()
+        B, L, H3 = qkv.shape
+        H = H3 // 3
+        d_o = d_o.to(torch.bfloat16).contiguous()
+        dqkv = torch.empty_like(qkv)
+        base, dbase = qkv.data_ptr(), dqkv.data_ptr()
+        N.check(L_.glr_attn_bwd(N.c_void_p(base), N.c_void_p(base + 2 * H), N.c_void_p(base + 4 * H), N.ptr(o), N.ptr(d_o),
+                                N.ptr(key_mask), N.ptr(lse), N.ptr(keep), B, nh, L, H3, H, scale, p, N.c_void_p(dbase),
+                                N.c_void_p(dbase + 2 * H), N.c_void_p(dbase + 4 * H), N.stream()), "glr_attn_bwd")
+        return dqkv, None, None, None, None
 
 
 def _fusable(q, k, v, key_mask, nh):
@@ -62,6 +100,18 @@ def _fusable(q, k, v, key_mask, nh):
     return (ENABLED and q.is_cuda and q.dtype == k.dtype == v.dtype == torch.bfloat16 and H == nh * 64 and L <= _max_tokens()
             and q.is_contiguous() and k.is_contiguous() and v.is_contiguous()
             and (key_mask is None or (key_mask.dtype == torch.bool and tuple(key_mask.shape) == (B, L) and key_mask.is_contiguous())))
+
+
+def packed_fusable(x, nh, hidden, L, key_mask):
+    """whether BertSelfAttention may run ONE query|key|value Linear and the packed kernels on input x"""
+    return (ENABLED and x.is_cuda and torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.bfloat16
+            and hidden == nh * 64 and L <= _max_tokens()
+            and (key_mask is None or (key_mask.dtype == torch.bool and key_mask.is_contiguous())))
+
+
+def self_attention_packed(qkv, key_mask, nh, p, training):
+    """qkv: bf16 [B, L, 3H] (query | key | value columns) -> context [B, L, H]"""
+    return _SelfAttnPacked.apply(qkv.contiguous(), key_mask, nh, p if training else 0.0, 1.0 / 8.0)
 
 
 def self_attention(q, k, v, key_mask, nh, p, training):

@@ -30,7 +30,7 @@ def _workspace(dev, n):
 
 class _BNAct(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, residual, weight, bias, run_mean, run_var, eps, momentum, relu):
+    def forward(ctx, x, residual, weight, bias, run_mean, run_var, nbt, eps, momentum, relu):
         L = N.lib()
         n, c, h, w = x.shape
         R = n * h * w
@@ -39,7 +39,7 @@ class _BNAct(torch.autograd.Function):
         stats = torch.empty(2, c, dtype=torch.float32, device=dev)
         ws = _workspace(dev, L.glr_bn_workspace_floats(R, c))
         N.check(L.glr_bn_act_fwd(N.ptr(x), N.ptr(residual), N.ptr(weight), N.ptr(bias), R, c, float(eps), float(momentum),
-                                 1 if relu else 0, N.ptr(run_mean), N.ptr(run_var), N.ptr(stats[0]), N.ptr(stats[1]),
+                                 1 if relu else 0, N.ptr(run_mean), N.ptr(run_var), N.ptr(nbt), stats.data_ptr(), stats.data_ptr() + 4 * c,
                                  N.ptr(ws), N.ptr(y), N.stream()), "glr_bn_act_fwd")
         ctx.save_for_backward(x, y if residual is not None else None, weight, bias, stats)
         ctx.relu, ctx.has_res = bool(relu), residual is not None
@@ -58,10 +58,10 @@ class _BNAct(torch.autograd.Function):
         dres = torch.empty_like(x) if ctx.has_res else None
         out = torch.empty(4, c, dtype=torch.float32, device=dev)
         ws = _workspace(dev, L.glr_bn_workspace_floats(R, c))
-        N.check(L.glr_bn_act_bwd(N.ptr(x), N.ptr(dy), N.ptr(y), N.ptr(weight), N.ptr(bias), N.ptr(stats[0]), N.ptr(stats[1]),
+        N.check(L.glr_bn_act_bwd(N.ptr(x), N.ptr(dy), N.ptr(y), N.ptr(weight), N.ptr(bias), stats.data_ptr(), stats.data_ptr() + 4 * c,
                                  R, c, 1 if ctx.relu else 0, 1 if ctx.has_res else 0, N.ptr(ws), N.ptr(out), N.ptr(dx),
                                  N.ptr(dres), N.stream()), "glr_bn_act_bwd")
-        return dx, dres, out[0], out[1], None, None, None, None, None
+        return dx, dres, out[0], out[1], None, None, None, None, None, None
 
 
 def _fusable(bn, x, residual):
@@ -77,8 +77,8 @@ def _fusable(bn, x, residual):
 def fused_bn_act(bn, x, residual=None, relu=True):
     """relu?(bn(x) (+ residual)) with nn.BatchNorm2d `bn`'s parameters and running statistics."""
     if _fusable(bn, x, residual):
-        bn.num_batches_tracked.add_(1)
-        return _BNAct.apply(x, residual, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, bn.momentum, relu)
+        return _BNAct.apply(x, residual, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked, bn.eps,
+                            bn.momentum, relu)
     out = bn(x)
     if residual is not None:
         out = out + residual

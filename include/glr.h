@@ -338,7 +338,8 @@ int glr_threshold_counts(const float* pred, const uint8_t* target, const float* 
  * gloria/models/cnn_backbones.py:31-35, vision_model.py:67-86).  x / y / dy / dx / residual / dres: bf16
  * [R = N*H*W, C] (NHWC memory), C a power of two in [8, 2048].
  *   fwd   mean, invstd [C] out (batch statistics, biased variance + eps); run_mean / run_var updated with
- *         `momentum` and the unbiased variance like nn.BatchNorm2d (NULL = no running statistics);
+ *         `momentum` and the unbiased variance like nn.BatchNorm2d (NULL = no running statistics); num_batches_tracked
+ *         (int64 scalar, NULL = none) is incremented by the same launch;
  *         y = relu?( (x - mean) invstd gamma + beta (+ residual) )
  *   bwd   dx; out4c = [dgamma | dbeta | 2C floats of scratch]; with a residual also dres = dy * [y > 0] (the
  *         gradient of the skip branch), y = the forward's output
@@ -347,8 +348,8 @@ int glr_threshold_counts(const float* pred, const uint8_t* target, const float* 
  */
 int glr_bn_workspace_floats(long long R, int C);
 int glr_bn_act_fwd(const void* x, const void* residual, const float* gamma, const float* beta, long long R, int C,
-                   float eps, float momentum, int relu, float* run_mean, float* run_var, float* mean, float* invstd,
-                   float* workspace, void* y, void* stream);
+                   float eps, float momentum, int relu, float* run_mean, float* run_var, long long* num_batches_tracked,
+                   float* mean, float* invstd, float* workspace, void* y, void* stream);
 int glr_bn_act_bwd(const void* x, const void* dy, const void* y, const float* gamma, const float* beta, const float* mean,
                    const float* invstd, long long R, int C, int relu, int has_residual, float* workspace, float* out4c,
                    void* dx, void* dres, void* stream);
@@ -377,8 +378,9 @@ int glr_drop_add_ln_bwd(const float* dy32, const void* dy16, const void* h16, co
  * Self-attention of the BERT text encoder for short captions (reference: BertSelfAttention of
  * transformers' BertModel, gloria/models/text_model.py:18-20; 97 tokens in imagenome_pretrain_config.yaml):
  *   O = dropout(softmax(Q K^T * scale + key mask)) V      per (sentence, head), head size 64, L <= 128 tokens.
- * q, k, v, o, d_o, dq, dk, dv: bf16 [B, L, ld] with head h in columns [64 h, 64 h + 64) (the Linear outputs read in
- * place, ld = hidden size); key_mask uint8 [B, L] (nonzero = attend) or NULL; lse fp32 [B * n_heads, 128] (row
+ * q, k, v, dq, dk, dv: bf16 rows of ld elements, o, d_o: rows of ld_o elements, head h in columns [64 h, 64 h + 64) (the
+ * Linear outputs read in place: ld = hidden size for three Linears, 3 x hidden for one fused query|key|value Linear whose
+ * three column blocks are passed as q, k, v); key_mask uint8 [B, L] (nonzero = attend) or NULL; lse fp32 [B * n_heads, 128] (row
  * log-sum-exp, saved for the backward); keep uint32 [B * n_heads, 128, 4]: dropout keep bits, key 32 j + i of query
  * row r = bit i of word (r, j) (NULL when p_drop == 0).  seed / offset: Philox4x32-10 key / counter prefix.
  * One workgroup per (sentence, head); glr_attn_max_tokens(backward) = largest L whose operands fit the 160 KB LDS
@@ -386,10 +388,10 @@ int glr_drop_add_ln_bwd(const float* dy32, const void* dy16, const void* h16, co
  */
 int glr_attn_max_tokens(int backward);
 int glr_attn_fwd(const void* q, const void* k, const void* v, const uint8_t* key_mask, int B, int n_heads, int L, int ld,
-                 float scale, float p_drop, unsigned long long seed, unsigned long long offset, void* o, float* lse,
+                 int ld_o, float scale, float p_drop, unsigned long long seed, unsigned long long offset, void* o, float* lse,
                  uint32_t* keep, void* stream);
 int glr_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o, const uint8_t* key_mask,
-                 const float* lse, const uint32_t* keep, int B, int n_heads, int L, int ld, float scale, float p_drop,
+                 const float* lse, const uint32_t* keep, int B, int n_heads, int L, int ld, int ld_o, float scale, float p_drop,
                  void* dq, void* dk, void* dv, void* stream);
 
 /* ------------------------------------------------------------------------------------------

@@ -48,7 +48,7 @@ def test_attention_matches_torch(B, nh, L, p, ragged):
     lse = torch.empty(B * nh, 128, device=DEV)
     keep = torch.zeros(B * nh, 128, 4, dtype=torch.int32, device=DEV) if p > 0 else None
     scale = 1.0 / math.sqrt(64)
-    N.check(Lb.glr_attn_fwd(N.ptr(q), N.ptr(k), N.ptr(v), N.ptr(key_mask), B, nh, L, H, scale, p, 99, 4, N.ptr(o), N.ptr(lse),
+    N.check(Lb.glr_attn_fwd(N.ptr(q), N.ptr(k), N.ptr(v), N.ptr(key_mask), B, nh, L, H, H, scale, p, 99, 4, N.ptr(o), N.ptr(lse),
                             N.ptr(keep), N.stream()), "fwd")
     km = None
     if p > 0:
@@ -63,7 +63,7 @@ def test_attention_matches_torch(B, nh, L, p, ragged):
     np.testing.assert_allclose(o.float().cpu().numpy() / scale_o, ref.detach().cpu().numpy() / scale_o, atol=1.5e-2)
     (ref * d_o.float()).sum().backward()
     dq, dk, dv = torch.empty_like(q), torch.empty_like(q), torch.empty_like(q)
-    N.check(Lb.glr_attn_bwd(N.ptr(q), N.ptr(k), N.ptr(v), N.ptr(o), N.ptr(d_o), N.ptr(key_mask), N.ptr(lse), N.ptr(keep), B, nh, L, H,
+    N.check(Lb.glr_attn_bwd(N.ptr(q), N.ptr(k), N.ptr(v), N.ptr(o), N.ptr(d_o), N.ptr(key_mask), N.ptr(lse), N.ptr(keep), B, nh, L, H, H,
                             scale, p, N.ptr(dq), N.ptr(dk), N.ptr(dv), N.stream()), "bwd")
     for name, got, want in (("dq", dq, qr.grad), ("dk", dk, kr.grad), ("dv", dv, vr.grad)):
         assert torch.isfinite(got.float()).all()
