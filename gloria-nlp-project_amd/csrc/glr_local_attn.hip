@@ -87,6 +87,8 @@ struct LaParams {
   int pair_only, img_offset;
   int img_block;                // pair kernel: images per L2 group (block -> (image, item) mapping)
   const int* pair_desc;         // [n_pair][64] sentences + row flags of every forward pair (glr_plan_pair_desc)
+  unsigned* a1buf;              // optional [B_img][n_pair][8 waves][2][3][8][64] fp16 pairs of a1 in the pair kernels' own
+                                // register order: written by the forward, read by the backward instead of its score stream
 #ifdef GLR_ABLATE
   int dbg;                      // diagnostic build only (libglr_ablate.so): phases to SKIP, GLR_K1_DBG bit mask
 #endif
@@ -1124,6 +1126,8 @@ __global__ void __launch_bounds__(NTHR) k_local_attn_pw(LaParams p) {
     // finite garbage that no sentence ever reads.
     if (!GLR_SKIP(4)) {
       float lc[3] = {0.f, 0.f, 0.f};
+      unsigned* a1out = p.a1buf == nullptr ? nullptr
+                        : p.a1buf + (((size_t)b * p.n_items + rem / ib) * 8 + wave) * (2 * 3 * 8 * 64) + lane;
       unsigned char* imgw = img0 + t * IMG + (4 * h) * IMP + rbase * ESZ;   // + (blk * 32 + row(q)) * IMP + 128 * j * ESZ
       float* redt = red + t * 16 * TW + rslot * TW + 4 * h;                // + blk * 32 + row(q)
 #pragma unroll
@@ -1131,6 +1135,7 @@ __global__ void __launch_bounds__(NTHR) k_local_attn_pw(LaParams p) {
         f32x16(&acc)[3] = blk == 0 ? acc0 : acc1;
         unsigned(&e2k)[3][8] = blk == 0 ? e2k0 : e2k1;
         float dq[16];                           // per-row partial dot~: reduced across lanes after the block (ILP)
+        float a1e[3] = {0.f, 0.f, 0.f};
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
           const int k = blk * 16 + q;
@@ -1148,6 +1153,19 @@ __global__ void __launch_bounds__(NTHR) k_local_attn_pw(LaParams p) {
 #pragma unroll
           for (int j = 0; j < 3; ++j) {
             const float a1 = __builtin_amdgcn_exp2f(__builtin_fmaf(acc[j][q], LOG2E, -lc[j]));
+            if (a1out != nullptr) {
+              // hand a1 to the backward (fp16 pairs of rows q, q + 1; one coalesced 256-byte store per wave instruction)
+              // (clamped: an empty word slot sees a stale lse and may give inf, which the backward must never meet)
+              float a1c;
+              asm("v_min_f32 %0, 1.0, %1" : "=v"(a1c) : "v"(a1));
+              if (q & 1) {
+                unsigned pk;
+                asm volatile("v_cvt_pkrtz_f16_f32 %0, %1, %2" : "=v"(pk) : "v"(a1e[j]), "v"(a1c));
+                a1out[((blk * 3 + j) * 8 + (q >> 1)) * 64] = pk;
+              } else {
+                a1e[j] = a1c;
+              }
+            }
             const float e2 = __builtin_amdgcn_exp2f(t1l * a1);
             O::from_f32(imgw + row * IMP + 128 * j * ESZ, e2);
             const float e2r = ESZ == 4 ? e2 : bf2f(f2bf(e2));
@@ -1305,7 +1323,9 @@ __global__ void __launch_bounds__(NTHR) k_local_attn_pw(LaParams p) {
 //           X = acc - a1 rho -> image -> xout
 // Optional third output baout = the P3 operand image beta a2 (saves the caller an elementwise pass in front of the
 // P = (beta a2)^T a2 GEMM).  Empty word slots have zero scalars: their rows of every output are exact zeros.
-template <typename O>
+// A1IN: the forward pair kernel handed over a1 (LaParams::a1buf, fp16 pairs in this kernel's own register order): no
+// score stream; the score itself, needed for -alpha s, is lse + log(a1).
+template <typename O, bool A1IN>
 __global__ void __launch_bounds__(NTHR) k_local_attn_pw_bwd(LaParams p) {
   constexpr int ESZ = O::ESZ, CB = CHB;
   constexpr int SP = GLR_MAX_SPAD;
@@ -1313,7 +1333,7 @@ __global__ void __launch_bounds__(NTHR) k_local_attn_pw_bwd(LaParams p) {
   constexpr int IMP = SP * ESZ + 16;
   constexpr int IMG = TW * IMP;
   constexpr int PPR = SP * ESZ / 16;                              // 16-byte pieces per output row
-  constexpr float LOG2E = 1.4426950408889634f;
+  constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
   constexpr int LT_OFF = NBUF * (2 * TW + SP) * CB;               // first byte past the P1 ring
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
@@ -1331,6 +1351,15 @@ __global__ void __launch_bounds__(NTHR) k_local_attn_pw_bwd(LaParams p) {
   GLR_STAMP2(0);
   const int tile0 = p.item_tile[rem / ib];
   const int D = p.D;
+  unsigned a1k0[3][8], a1k1[3][8];                                // a1 as fp16 pairs (rows q, q + 1)
+  if constexpr (A1IN) {
+    // 48 coalesced dword loads per lane, in flight behind the whole set-up
+    const unsigned* a1in = p.a1buf + (((size_t)b * p.n_items + rem / ib) * 8 + wave) * (2 * 3 * 8 * 64) + lane;
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { a1k0[j][i] = a1in[(j * 8 + i) * 64]; a1k1[j][i] = a1in[((3 + j) * 8 + i) * 64]; }
+  }
 
   unsigned char* ring = smem;
   unsigned char* img0 = smem;
@@ -1424,6 +1453,7 @@ __global__ void __launch_bounds__(NTHR) k_local_attn_pw_bwd(LaParams p) {
   for (int j = 0; j < 3; ++j)
 #pragma unroll
     for (int q = 0; q < 16; ++q) { acc0[j][q] = 0.f; acc1[j][q] = 0.f; }
+  if constexpr (!A1IN)
   if (!GLR_SKIP(1))
   stream_gemm<O, false, 2>(acc0, acc1, t * TW, 32 * CB, ring, (2 * TW + SP) * CB, p.tp + (size_t)tile0 * TW * rowbytes1,
                            rowbytes1, vt_b, rowbytes1, SP, (int)(rowbytes1 / CB), nullptr, 0, wave, lane, 0, wg, NRB, TW);
@@ -1442,7 +1472,6 @@ __global__ void __launch_bounds__(NTHR) k_local_attn_pw_bwd(LaParams p) {
   const int rbase = wg * 32 + l31;
   const float t1l = p.temp1 * LOG2E;
   const float ok2 = (rbase + 256 < p.S_eff) ? 1.f : 0.f;          // padded regions live in block 2 only
-  unsigned a1k0[3][8], a1k1[3][8];                                // a1 as fp16 pairs (rows q, q + 1)
   unsigned char* imgw = img0 + t * IMG + (4 * h) * IMP + rbase * ESZ;
   const float4* w4t = w4 + t * TW + 4 * h;
 
@@ -1453,7 +1482,7 @@ __global__ void __launch_bounds__(NTHR) k_local_attn_pw_bwd(LaParams p) {
     for (int blk = 0; blk < 2; ++blk) {
       f32x16(&acc)[3] = blk == 0 ? acc0 : acc1;
       unsigned(&a1k)[3][8] = blk == 0 ? a1k0 : a1k1;
-      float a1e[3] = {0.f, 0.f, 0.f};
+      [[maybe_unused]] float a1e[3] = {0.f, 0.f, 0.f};
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         const int k = blk * 16 + q;
@@ -1470,15 +1499,25 @@ __global__ void __launch_bounds__(NTHR) k_local_attn_pw_bwd(LaParams p) {
         const float4 w = w4t[row];
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-          float x = __builtin_fmaf(acc[j][q], LOG2E, -lc[j]);
-          asm("v_min_f32 %0, 0, %1" : "=v"(x) : "v"(x));          // empty slots: stale lse, keep a1 finite
-          const float a1 = __builtin_amdgcn_exp2f(x);
+          float a1, sc;
+          if constexpr (A1IN) {
+            const h2 hp = __builtin_bit_cast(h2, a1k[j][q >> 1]);
+            a1 = (float)((q & 1) ? hp.y : hp.x);                      // <= 1: the forward clamps what it hands over
+            sc = (lc[j] + __builtin_amdgcn_logf(fmaxf(a1, 5.9604645e-8f))) * LN2;     // s = lse + log a1
+          } else {
+            float x = __builtin_fmaf(acc[j][q], LOG2E, -lc[j]);
+            asm("v_min_f32 %0, 0, %1" : "=v"(x) : "v"(x));        // empty slots: stale lse, keep a1 finite
+            a1 = __builtin_amdgcn_exp2f(x);
+            sc = acc[j][q];
+          }
           const float a2 = __builtin_amdgcn_exp2f(t1l * a1) * w.x;
           O::from_f32(imgw + row * IMP + 128 * j * ESZ, w.y * a2);
-          // (volatile: the compiler otherwise sinks the conversion to its use behind P3 and keeps - spills - 96 fp32 values)
-          if (q & 1) asm volatile("v_cvt_pkrtz_f16_f32 %0, %1, %2" : "=v"(a1k[j][q >> 1]) : "v"(a1e[j]), "v"(a1));
-          else a1e[j] = a1;
-          acc[j][q] = -w.z * acc[j][q];
+          if constexpr (!A1IN) {
+            // (volatile: the compiler otherwise sinks the conversion to its use behind P3 and keeps - spills - 96 fp32 values)
+            if (q & 1) asm volatile("v_cvt_pkrtz_f16_f32 %0, %1, %2" : "=v"(a1k[j][q >> 1]) : "v"(a1e[j]), "v"(a1));
+            else a1e[j] = a1;
+          }
+          acc[j][q] = -w.z * sc;
           asm volatile("" : "+v"(acc[j][q]));                   // computed HERE (not sunk to its use behind the barrier)
         }
       }
@@ -1504,6 +1543,13 @@ __global__ void __launch_bounds__(NTHR) k_local_attn_pw_bwd(LaParams p) {
   }
 
   // ================= A: da1, run sums of a1 da1, a2 image =================
+  if constexpr (A1IN) {
+    // (opaque copies: the compiler otherwise keeps P2's unpacked fp32 a1 alive - spilled - for this pass)
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { asm volatile("" : "+v"(a1k0[j][i])); asm volatile("" : "+v"(a1k1[j][i])); }
+  }
   GLR_STAMP2(5);
   const int nrow = long_pair ? 2 : NS;
   {
@@ -1708,8 +1754,13 @@ int launch_pair_bwd(LaParams& p, int op_dtype, void* stream) {
 #ifdef GLR_ABLATE
   { const char* e = getenv("GLR_K1_DBG"); p.dbg = e ? atoi(e) : 0; }
 #endif
-  if (hipFuncSetAttribute((const void*)k_local_attn_pw_bwd<OpBF16>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return GLR_ELAUNCH;
-  hipLaunchKernelGGL((k_local_attn_pw_bwd<OpBF16>), dim3(grid), dim3(NTHR), lds, (hipStream_t)stream, p);
+  if (p.a1buf != nullptr) {
+    if (hipFuncSetAttribute((const void*)k_local_attn_pw_bwd<OpBF16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return GLR_ELAUNCH;
+    hipLaunchKernelGGL((k_local_attn_pw_bwd<OpBF16, true>), dim3(grid), dim3(NTHR), lds, (hipStream_t)stream, p);
+  } else {
+    if (hipFuncSetAttribute((const void*)k_local_attn_pw_bwd<OpBF16, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return GLR_ELAUNCH;
+    hipLaunchKernelGGL((k_local_attn_pw_bwd<OpBF16, false>), dim3(grid), dim3(NTHR), lds, (hipStream_t)stream, p);
+  }
   GLR_CHECK_LAUNCH();
   return GLR_OK;
 }
@@ -1726,7 +1777,7 @@ int fill_common(LaParams& p, const void* vt, const void* gram, const void* tp, c
   if (agg < 0 || agg > 2) return GLR_EINVAL;
   p.vt = (const unsigned char*)vt; p.gram = (const unsigned char*)gram; p.tp = (const unsigned char*)tp;
   p.tnorm = tnorm; p.sent_slot0 = sent_slot0; p.cap_lens = cap_lens; p.tile_first = tile_first; p.order = order;
-  p.tile_nsub = tile_nsub; p.item_tile = nullptr; p.n_items = 0; p.amean = nullptr; p.damean = nullptr; p.dattn = nullptr; p.pair_desc = nullptr; p.n_tiles = n_tiles; p.n_sent = n_sent;
+  p.tile_nsub = tile_nsub; p.item_tile = nullptr; p.n_items = 0; p.amean = nullptr; p.damean = nullptr; p.dattn = nullptr; p.pair_desc = nullptr; p.a1buf = nullptr; p.n_tiles = n_tiles; p.n_sent = n_sent;
   p.n_slots = n_tiles * TW; p.B_img = B_img;
   p.D = D; p.S_eff = S_eff; p.S_pad = S_pad; p.temp1 = temp1; p.temp2 = temp2; p.temp3 = temp3; p.agg = agg;
   p.eps = eps;
@@ -1751,7 +1802,7 @@ extern "C" int glr_local_attn_fwd(const void* vt, const void* gram, const void* 
                                   int n_tiles, int n_sent, int B_img, int D, int S_eff, float temp1, float temp2,
                                   float temp3, int agg, float eps, float* sim, int ld_sim, float* lse, float* wstat,
                                   float* attn, const int64_t* attn_off, int strip, int pair_only, int img_offset,
-                                  float* amean, int op_dtype, void* stream) {
+                                  float* amean, void* a1buf, int op_dtype, void* stream) {
   LaParams p;
   int rc = fill_common(p, vt, gram, tp, tnorm, sent_slot0, cap_lens, tile_first, order, tile_nsub, n_tiles,
                        n_sent, B_img, D, S_eff, temp1, temp2, temp3, agg, eps, op_dtype);
@@ -1769,7 +1820,7 @@ extern "C" int glr_local_attn_fwd(const void* vt, const void* gram, const void* 
     if (rc != GLR_OK) return rc;
   }
   if (!pair_only && n_pair > 0) {
-    p.item_tile = pair_tile; p.n_items = n_pair; p.pair_desc = pair_desc;
+    p.item_tile = pair_tile; p.n_items = n_pair; p.pair_desc = pair_desc; p.a1buf = (unsigned*)a1buf;
     rc = launch_pair(p, op_dtype, stream);
   }
   return rc;
@@ -1784,7 +1835,7 @@ extern "C" int glr_local_attn_bwd(const void* vt, const void* gram, const void* 
                                   const float* sim, const float* dsim, int ld_sim, const float* lse,
                                   const float* wstat, const float* damean, const float* dattn,
                                   const int64_t* attn_off, int strip, int img_offset, void* xout, void* aout,
-                                  void* baout, float* gamma, float* beta, int op_dtype, void* stream) {
+                                  void* baout, float* gamma, float* beta, const void* a1buf, int op_dtype, void* stream) {
   LaParams p;
   int rc = fill_common(p, vt, gram, tp, tnorm, sent_slot0, cap_lens, tile_first, order, tile_nsub, n_tiles,
                        n_sent, B_img, D, S_eff, temp1, temp2, temp3, agg, eps, op_dtype);
@@ -1806,7 +1857,7 @@ extern "C" int glr_local_attn_bwd(const void* vt, const void* gram, const void* 
     if (rc != GLR_OK) return rc;
   }
   if (n_pair > 0) {
-    p.item_tile = pair_tile; p.n_items = n_pair; p.pair_desc = pair_desc;
+    p.item_tile = pair_tile; p.n_items = n_pair; p.pair_desc = pair_desc; p.a1buf = (unsigned*)const_cast<void*>(a1buf);
     rc = launch_pair_bwd(p, op_dtype, stream);
   }
   return rc;

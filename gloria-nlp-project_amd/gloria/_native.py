@@ -37,13 +37,13 @@ SYMBOLS = {
     "glr_pack_words": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                c_int, c_int, c_int, c_void_p]),
     "glr_local_attn_fwd": (c_int, [c_void_p] * 10 + [c_int, c_void_p, c_int, c_void_p] + [c_int] * 5 + [c_float] * 3 + [c_int, c_float, c_void_p, c_int,
-                                   c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
-                                   # ..., sim, ld, lse, wstat, attn, attn_off, strip, pair_only, img_offset, amean, dtype, stream
+                                   c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]),
+                                   # ..., sim, ld, lse, wstat, attn, attn_off, strip, pair_only, img_offset, amean, a1buf, dtype, stream
     "glr_local_attn_bwd": (c_int, [c_void_p] * 10 + [c_int, c_void_p, c_int, c_void_p] + [c_int] * 5 + [c_float] * 3
                            + [c_int, c_float, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                              c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+                              c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
                                    # sim, dsim, ld, lse, wstat, damean, dattn, attn_off, strip, img_offset,
-                                   # xout, aout, baout, gamma, beta, dtype, stream
+                                   # xout, aout, baout, gamma, beta, a1buf, dtype, stream
     "glr_sumsq_blocks": (c_int, [ctypes.c_longlong]),
     "glr_gather_mt": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p]),
     "glr_sumsq_mt": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p]),

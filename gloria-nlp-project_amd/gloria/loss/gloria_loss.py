@@ -18,6 +18,8 @@ Differences that are deliberate and documented in DESIGN.md:
 from typing import List, Optional, Sequence
 
 import numpy as np
+import os
+
 import torch
 
 from .. import _native as N
@@ -30,6 +32,8 @@ _COMPUTE_DTYPE = None          # None = follow the input dtype
 #   "k1_bwd"     the K1 backward launch alone                "k1_bwd_op"  K1 backward + gradient GEMMs + scatter
 # and "k1_flops": algorithmic forward FLOPs of every forward call.
 PROFILE = None
+_DEBUG_HOOK = None          # diagnostics only: called with the K1 backward outputs (tools)
+HANDOVER_A1 = os.environ.get("GLR_K1_A1", "1") != "0"     # forward -> backward hand-over of a1 (A/B switch)
 
 
 class _Range:
@@ -178,10 +182,15 @@ class LocalSimFn(torch.autograd.Function):
             attn_off, off_host = plan.attn_offsets(s_eff - strip, dev)
             attn = torch.zeros(int(off_host[-1]), dtype=torch.float32, device=dev)
         amean = torch.empty(B, n_sent, s_pad, dtype=torch.float32, device=dev) if o.want_amean else None
+        # the forward pair kernel hands the word-softmax values to the backward pair kernel (98 KB per image x pair, fp16,
+        # in the kernels' own register order): the backward then skips its score stream
+        a1buf = None
+        if need_grad and plan.n_pair and HANDOVER_A1 and not o.pair_only:
+            a1buf = torch.empty(B * plan.n_pair * 24576, dtype=torch.int32, device=dev)
         with _Range("k1_fwd"):
             N.check(L.glr_local_attn_fwd(*_k1_args(plan, vt_t, gram_t, tp_t, tnorm, B, D, s_eff, o), N.ptr(sim), n_sent,
                                          N.ptr(lse), N.ptr(wstat), N.ptr(attn), N.ptr(attn_off), strip,
-                                         1 if o.pair_only else 0, o.img_offset, N.ptr(amean), code, N.stream()),
+                                         1 if o.pair_only else 0, o.img_offset, N.ptr(amean), N.ptr(a1buf), code, N.stream()),
                     "glr_local_attn_fwd")
         op_range.__exit__()
         if PROFILE is not None:
@@ -193,7 +202,7 @@ class LocalSimFn(torch.autograd.Function):
             a2 = attn.view(B, n, s_eff)
             wctx = torch.bmm(a2.to(vt.dtype), vt[:, :s_eff]).transpose(1, 2).float().contiguous()   # [B, D, n]
             attn = a2[:, :, shift:].contiguous().view(-1)
-        ctx.save_for_backward(img_features, words_emb, no_attn_vec, vt, vt_t, gram_t, tp, tp_t, tnorm, sim, lse, wstat)
+        ctx.save_for_backward(img_features, words_emb, no_attn_vec, vt, vt_t, gram_t, tp, tp_t, tnorm, sim, lse, wstat, a1buf)
         ctx.plan, ctx.opts, ctx.meta = plan, o, (code, s_eff, s_pad, shift)
         ctx.set_materialize_grads(False)       # unused outputs (maps, context) arrive as None
         if attn is None:
@@ -206,7 +215,7 @@ class LocalSimFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dsim, dattn, dwctx, damean):
-        img_features, words_emb, no_attn_vec, vt, vt_t, gram_t, tp, tp_t, tnorm, sim, lse, wstat = ctx.saved_tensors
+        img_features, words_emb, no_attn_vec, vt, vt_t, gram_t, tp, tp_t, tnorm, sim, lse, wstat, a1buf = ctx.saved_tensors
         plan, o = ctx.plan, ctx.opts
         code, s_eff, s_pad, shift = ctx.meta
         L = N.lib()
@@ -246,7 +255,9 @@ class LocalSimFn(torch.autograd.Function):
                 N.check(L.glr_local_attn_bwd(*_k1_args(plan, vt_t, gram_t, tp_t, tnorm, B, D, s_eff, o, mode), N.ptr(sim),
                                              N.ptr(g), plan.n_sent, N.ptr(lse), N.ptr(wstat), N.ptr(dam), N.ptr(dat),
                                              N.ptr(dat_off), strip, o.img_offset, N.ptr(xout), N.ptr(aout), N.ptr(baout),
-                                             N.ptr(gamma), N.ptr(beta), code, N.stream()), "glr_local_attn_bwd")
+                                             N.ptr(gamma), N.ptr(beta), N.ptr(a1buf), code, N.stream()), "glr_local_attn_bwd")
+            if _DEBUG_HOOK is not None:
+                _DEBUG_HOOK(xout, aout, baout, gamma, beta)
             # gradient GEMMs (plain library GEMMs on the kernel's outputs)
             x2d = xout.view(ns, B * s_pad)
             dtp = (x2d @ vt.view(B * s_pad, D)).float() - gamma.sum(0).unsqueeze(1) * tp.float()      # [ns, D]

@@ -193,6 +193,10 @@ int glr_pack_words(const void* words_emb, int in_dtype, const int32_t* sent_slot
  *                kernel's own second-contraction operand holds it
  *   gamma [B_img, n_slots] fp32              coefficient of T_w in dT (from the word norm)
  * with X2d = xout viewed [n_slots, B_img*S_pad] and vt2d = vt viewed [B_img*S_pad, D].
+ *   a1buf  optional, both directions (NULL = none): n_pair * B_img * 98304 bytes.  The forward pair kernel leaves the
+ *          word-softmax values a1 of every pair there (fp16, in the pair kernels' own register order - opaque to the
+ *          caller); given the same buffer, the backward pair kernel reads them instead of re-streaming vt[b] and the
+ *          word tiles for the scores (s = lse + log a1).
  * The backward takes the forward's work items: single tiles and (bf16, 384 regions, no damean / dattn) pairs with
  * their descriptors; with damean / dattn every tile must be passed as a single tile.
  */
@@ -202,7 +206,7 @@ int glr_local_attn_fwd(const void* vt, const void* gram, const void* tp, const f
                        const int32_t* pair_tile, int n_pair, const int32_t* pair_desc, int n_tiles, int n_sent,
                        int B_img, int D, int S_eff, float temp1, float temp2, float temp3, int agg, float eps,
                        float* sim, int ld_sim, float* lse, float* wstat, float* attn, const int64_t* attn_off,
-                       int strip, int pair_only, int img_offset, float* amean, int op_dtype, void* stream);
+                       int strip, int pair_only, int img_offset, float* amean, void* a1buf, int op_dtype, void* stream);
 
 int glr_local_attn_bwd(const void* vt, const void* gram, const void* tp, const float* tnorm,
                        const int32_t* sent_slot0, const int32_t* cap_lens, const int32_t* tile_first,
@@ -212,7 +216,7 @@ int glr_local_attn_bwd(const void* vt, const void* gram, const void* tp, const f
                        int agg, float eps, const float* sim, const float* dsim, int ld_sim, const float* lse,
                        const float* wstat, const float* damean, const float* dattn, const int64_t* attn_off,
                        int strip, int img_offset, void* xout, void* aout, void* baout, float* gamma, float* beta,
-                       int op_dtype, void* stream);
+                       const void* a1buf, int op_dtype, void* stream);
 
 /* K-tiling of the K1 operands (device, HBM-bound copy).  glr_local_attn_fwd / _bwd take vt, gram and tp in
  * the K-TILED layout: every block of `rows` rows (vt, gram: the S_pad rows of one image; tp: the 64 slots of one

@@ -26,7 +26,13 @@ rm -rf "$OUT/prof_k1"
 say "PMC passes, K1 forward"; PASS_TIMEOUT=100 bash tools/pmc_k1.sh ${TAG}_fwd fwd > "$OUT/pmc_fwd.log" 2>&1
 say "PMC passes, K1 forward + backward"; PASS_TIMEOUT=100 bash tools/pmc_k1.sh ${TAG}_bwd bwd > "$OUT/pmc_bwd.log" 2>&1
 say "ablation"; timeout -k 10 200 python tools/ablate_k1.py > "$OUT/ablate.txt" 2>&1
+say "ablation, backward"; timeout -k 10 200 python tools/ablate_k1_bwd.py > "$OUT/ablate_bwd.txt" 2>&1
 say "stamps"; timeout -k 10 200 python tools/stamps_k1.py > "$OUT/stamps.txt" 2>&1
+timeout -k 10 200 python tools/stamps_k1.py bwd > "$OUT/stamps_bwd.txt" 2>&1
+say "encoder micro-benchmarks"; timeout -k 10 200 python tools/bench_bn.py > "$OUT/bench_bn.txt" 2>&1
+(cd /tmp && export TMPDIR=/tmp && timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_attn" -- python3 "$ROOT/tools/bench_attn.py" > "$OUT/bench_attn.txt" 2>&1)
+grep -h "attn\|bwd_kernel" "$OUT"/prof_attn/*/*kernel_stats.csv > "$OUT/attn_kernel_stats.csv" 2>/dev/null
+rm -rf "$OUT/prof_attn"
 say "K3"; (cd /tmp && export TMPDIR=/tmp && timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_k3" -- python3 "$ROOT/tools/bench_k3.py" > "$OUT/k3.log" 2>&1)
 grep -h "k_global\|k_ce" "$OUT"/prof_k3/*/*kernel_stats.csv > "$OUT/k3_kernel_stats.csv" 2>/dev/null
 rm -rf "$OUT/prof_k3"
