@@ -9,11 +9,13 @@
 //             32w..32w+31: S (16 MFMA 32x32x16),
 //             row softmax across the 32 lanes of a lane half (DPP butterflies), dropout, P -> the wave's LDS slab,
 //             O = P V (2 x L/16 MFMA).  Saves lse per row and the dropout keep bits (1 bit per score).
-//   backward  two wave-independent passes after one cooperative load, no atomics, no cross-wave reductions:
+//   backward  two passes, each a kernel of its own (56 / 72 KB of LDS: two workgroups per CU), waves independent after
+//             the cooperative load, no atomics, no cross-wave reductions:
 //             pass Q (wave owns 32 queries): S, dP = dO V^T, dS -> slab, dQ = dS K;
 //             pass K (wave owns 32 keys):    S^T = K Q^T, dP^T = V dO^T (the same products with the operands
 //             swapped land key-major in the accumulators), P^T -> slab, dV = P^T dO, dS^T -> slab, dK = dS^T Q.
-//             Every product is an "A . B^T" of two k-contiguous LDS operands; the three operands that are contracted
+//             Every product is an "A . B^T" of two k-contiguous operands: the wave's own rows come straight from
+//             global memory as MFMA fragments, the other side sits in LDS; the three operands that are contracted
 //             over tokens (K for dQ, dO for dV, Q for dK) get a transposed LDS copy at load time.
 // Tensors are the [B, L, n_heads * 64] outputs of the query / key / value Linears read in place (row stride = hidden
 // size); O and the gradients are written in the same layout, so no permute / contiguous copies exist around the op.
@@ -244,60 +246,81 @@ __global__ void __launch_bounds__(AT_NT) k_attn_fwd(AttnParams p) {
   store_rows(out, slab, tp, p.o + (size_t)b * L * p.ld_o + (size_t)hd * 64, p.ld_o, row0, L, lane, l31, h);
 }
 
-__global__ void __launch_bounds__(AT_NT) k_attn_bwd(AttnParams p) {
+// ---- backward, split by pass so that two workgroups fit a CU (56 / 72 KB of LDS instead of 155 KB in one kernel:
+// at one workgroup of four waves per CU every latency of the long dependent chains is exposed).  The wave's own 32
+// rows - the A operand of its score products - go straight from global memory into MFMA fragments; the B operands
+// are staged in LDS, and their space becomes the wave slabs once every wave has its two score tiles.
+__device__ __forceinline__ void frag_rows_load(const unsigned short* g, int ld, int row, int L, int h, bf16x8 (&f)[4]) {
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (row < L) v = *reinterpret_cast<const uint4*>(g + (size_t)row * ld + ks * 16 + h * 8);
+    f[ks] = __builtin_bit_cast(bf16x8, v);
+  }
+}
+__device__ __forceinline__ void gemm_frag64(f32x16 (&acc)[4], const bf16x8 (&fa)[4], const unsigned char* Bm, int nblk, int l31, int h) {
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (j < nblk) mma(fa[ks], ldf(Bm + (32 * j + l31) * AT_RP + ks * 32 + h * 16), acc[j]);
+}
+
+// pass Q: workgroup = (sentence, head), wave = 32 query rows: S, dP = dO V^T, dS -> slab, dQ = dS K
+__global__ void __launch_bounds__(AT_NT, 2) k_attn_bwd_q(AttnParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
   const int bh = blockIdx.x, b = bh / p.nh, hd = bh % p.nh;
   const int L = p.L, tp = p.tp, lk = (L + 15) & ~15, kt = lk >> 4, nkb = (L + 31) >> 5;
-  unsigned char* Qs = smem;
-  unsigned char* Ks = Qs + 128 * AT_RP;
+  unsigned char* Ks = smem;
   unsigned char* Vs = Ks + 128 * AT_RP;
-  unsigned char* Gs = Vs + 128 * AT_RP;          // dO
-  unsigned char* Qt = Gs + 128 * AT_RP;
-  unsigned char* Kt = Qt + 64 * tp;
-  unsigned char* Gt = Kt + 64 * tp;
-  unsigned char* Ps = Gt + 64 * tp;
-  float* kb = reinterpret_cast<float*>(Ps + 128 * AT_SP);
+  unsigned char* Kt = Vs + 128 * AT_RP;
+  unsigned char* Ps = smem;                      // slabs take the place of K / V
+  float* kb = reinterpret_cast<float*>(Kt + 64 * tp);
   float* lse = kb + 128;
-  float* delta = lse + 128;                                       // [2][128] partial sums (the two thread halves)
-  unsigned* keep = reinterpret_cast<unsigned*>(delta + 256);      // [128][4]
-  const size_t base = (size_t)b * L * p.ld + (size_t)hd * 64;
+  float* delta = lse + 128;                                       // [128], rows of wave w written by wave w
+  unsigned* keep = reinterpret_cast<unsigned*>(delta + 128);      // [128][4]
+  const size_t base = (size_t)b * L * p.ld + (size_t)hd * 64, base_o = (size_t)b * L * p.ld_o + (size_t)hd * 64;
   const bool drop = p.p_drop > 0.f;
+  const int row0 = 32 * wave;
+  const bool active = row0 < L;
+  bf16x8 fq[4], fg[4];
   {
-    uint4 rq[4], rk[4], rv[4], rg[4], ro[4];
-    tile_load(p.q + base, p.ld, L, rq, tid);
+    uint4 rk[4], rv[4];
+    bf16x8 fo[4];
     tile_load(p.k + base, p.ld, L, rk, tid);
     tile_load(p.v + base, p.ld, L, rv, tid);
-    tile_load(p.d_o + (size_t)b * L * p.ld_o + (size_t)hd * 64, p.ld_o, L, rg, tid);
-    tile_load(p.o + (size_t)b * L * p.ld_o + (size_t)hd * 64, p.ld_o, L, ro, tid);
+    frag_rows_load(p.q + base, p.ld, row0 + l31, L, h, fq);
+    frag_rows_load(p.d_o + base_o, p.ld_o, row0 + l31, L, h, fg);
+    frag_rows_load(p.o + base_o, p.ld_o, row0 + l31, L, h, fo);
     if (tid < 128) {
       kb[tid] = (tid < L && (p.key_mask == nullptr || p.key_mask[(size_t)b * L + tid] != 0)) ? 0.f : -INFINITY;
       lse[tid] = tid < L ? p.lse[(size_t)bh * 128 + tid] * AT_LOG2E : 0.f;
     }
     for (int i = tid; i < 512; i += AT_NT) keep[i] = (drop && (i >> 2) < L) ? p.keep[(size_t)bh * 512 + i] : 0xffffffffu;
-    tile_store_rows(rq, Qs, tid);
     tile_store_rows(rk, Ks, tid);
     tile_store_rows(rv, Vs, tid);
-    tile_store_rows(rg, Gs, tid);
-    tile_store_transposed(rq, lk, Qt, tp, tid);
     tile_store_transposed(rk, lk, Kt, tp, tid);
-    tile_store_transposed(rg, lk, Gt, tp, tid);
-    // delta[row] = <dO[row], O[row]>: thread tid holds pieces {2 t + (tid >> 7)} of row tid & 127 -> two partial sums per row
-    delta[tid] = (dot8(rg[0], ro[0]) + dot8(rg[1], ro[1])) + (dot8(rg[2], ro[2]) + dot8(rg[3], ro[3]));
+    // delta[row] = <dO[row], O[row]>: a lane holds half of its row (the k pieces of its lane half)
+    float d = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) d += dot8(__builtin_bit_cast(uint4, fg[ks]), __builtin_bit_cast(uint4, fo[ks]));
+    d += __shfl_xor(d, 32, 64);
+    if (h == 0) delta[row0 + l31] = d;
   }
   __syncthreads();
-  const int row0 = 32 * wave;
-  if (row0 >= L) return;                        // no barrier below
+  f32x16 acc[4], acc2[4], out[2];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { zero16(acc[j]); zero16(acc2[j]); }
+  if (active) {
+    gemm_frag64(acc, fq, Ks, nkb, l31, h);                 // S
+    gemm_frag64(acc2, fg, Vs, nkb, l31, h);                // dP (before the dropout scaling) = dO V^T
+  }
+  __syncthreads();                              // K / V rows are dead: their space becomes the slabs
+  if (!active) return;                          // no barrier below
   const float inv_keep = drop ? 1.f / (1.f - p.p_drop) : 1.f;
   const float sl = p.scale * AT_LOG2E;
   unsigned char* slab = Ps + wave * 32 * AT_SP;
-  f32x16 acc[4], acc2[4], out[2];
-
-  // ---------------- pass Q: this wave's 32 query rows ----------------
-#pragma unroll
-  for (int j = 0; j < 4; ++j) { zero16(acc[j]); zero16(acc2[j]); }
-  gemm_rows64(acc, Qs, row0, Ks, nkb, l31, h);            // S
-  gemm_rows64(acc2, Gs, row0, Vs, nkb, l31, h);           // dP (before the dropout scaling) = dO V^T
   {
     float kbv[4];
 #pragma unroll
@@ -305,7 +328,7 @@ __global__ void __launch_bounds__(AT_NT) k_attn_bwd(AttnParams p) {
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
       const int r = acc_row(q, h);
-      const float lr = lse[row0 + r], dl = delta[row0 + r] + delta[128 + row0 + r];
+      const float lr = lse[row0 + r], dl = delta[row0 + r];
       const uint4 kw = *reinterpret_cast<const uint4*>(keep + (row0 + r) * 4);
       const unsigned kwj[4] = {kw.x, kw.y, kw.z, kw.w};
 #pragma unroll
@@ -319,46 +342,90 @@ __global__ void __launch_bounds__(AT_NT) k_attn_bwd(AttnParams p) {
   zero16(out[0]); zero16(out[1]);
   gemm_tokens(out, slab, Kt, tp, kt, l31, h);             // dQ = dS K
   store_rows(out, slab, tp, p.dq + base, p.ld, row0, L, lane, l31, h);
+}
 
-  // ---------------- pass K: this wave's 32 key rows ----------------
+// pass K: wave = 32 key rows: S^T = K Q^T, dP^T = V dO^T, P^T -> slab, dV = P^T dO, dS^T -> slab, dK = dS^T Q
+__global__ void __launch_bounds__(AT_NT, 2) k_attn_bwd_kv(AttnParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
+  const int bh = blockIdx.x, b = bh / p.nh, hd = bh % p.nh;
+  const int L = p.L, tp = p.tp, lk = (L + 15) & ~15, kt = lk >> 4, nkb = (L + 31) >> 5;
+  unsigned char* Qs = smem;
+  unsigned char* Gs = Qs + 128 * AT_RP;          // dO
+  unsigned char* Qt = Gs + 128 * AT_RP;
+  unsigned char* Gt = Qt + 64 * tp;
+  unsigned char* Ps = smem;                      // slabs take the place of Q / dO rows
+  float* kb = reinterpret_cast<float*>(Gt + 64 * tp);
+  float* lse = kb + 128;
+  float* delta = lse + 128;                                       // [2][128] partial sums (the two thread halves)
+  unsigned* keep = reinterpret_cast<unsigned*>(delta + 256);      // [128][4]
+  const size_t base = (size_t)b * L * p.ld + (size_t)hd * 64, base_o = (size_t)b * L * p.ld_o + (size_t)hd * 64;
+  const bool drop = p.p_drop > 0.f;
+  const int row0 = 32 * wave;
+  const bool active = row0 < L;
+  bf16x8 fk[4], fv[4];
+  {
+    uint4 rq[4], rg[4], ro[4];
+    tile_load(p.q + base, p.ld, L, rq, tid);
+    tile_load(p.d_o + base_o, p.ld_o, L, rg, tid);
+    tile_load(p.o + base_o, p.ld_o, L, ro, tid);
+    frag_rows_load(p.k + base, p.ld, row0 + l31, L, h, fk);
+    frag_rows_load(p.v + base, p.ld, row0 + l31, L, h, fv);
+    if (tid < 128) {
+      kb[tid] = (tid < L && (p.key_mask == nullptr || p.key_mask[(size_t)b * L + tid] != 0)) ? 0.f : -INFINITY;
+      lse[tid] = tid < L ? p.lse[(size_t)bh * 128 + tid] * AT_LOG2E : 0.f;
+    }
+    for (int i = tid; i < 512; i += AT_NT) keep[i] = (drop && (i >> 2) < L) ? p.keep[(size_t)bh * 512 + i] : 0xffffffffu;
+    tile_store_rows(rq, Qs, tid);
+    tile_store_rows(rg, Gs, tid);
+    tile_store_transposed(rq, lk, Qt, tp, tid);
+    tile_store_transposed(rg, lk, Gt, tp, tid);
+    delta[tid] = (dot8(rg[0], ro[0]) + dot8(rg[1], ro[1])) + (dot8(rg[2], ro[2]) + dot8(rg[3], ro[3]));
+  }
+  __syncthreads();
+  f32x16 acc[4], acc2[4], out[2];
 #pragma unroll
   for (int j = 0; j < 4; ++j) { zero16(acc[j]); zero16(acc2[j]); }
-  gemm_rows64(acc, Ks, row0, Qs, nkb, l31, h);            // S^T
-  gemm_rows64(acc2, Vs, row0, Gs, nkb, l31, h);           // dP^T = V dO^T
-  {
-    float lq[4], dq_[4];
-    unsigned kwq[4];
+  float lq[4], dq_[4], kbk16[16];
+  unsigned kwq[4];
+  if (active) {
+    gemm_frag64(acc, fk, Qs, nkb, l31, h);                 // S^T
+    gemm_frag64(acc2, fv, Gs, nkb, l31, h);                // dP^T = V dO^T
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    lq[j] = lse[32 * j + l31];
+    dq_[j] = delta[32 * j + l31] + delta[128 + 32 * j + l31];
+    kwq[j] = keep[(32 * j + l31) * 4 + wave];            // keys of this wave's block, of query 32 j + l31
+  }
+#pragma unroll
+  for (int q = 0; q < 16; ++q) kbk16[q] = kb[row0 + acc_row(q, h)];
+  __syncthreads();                              // Q / dO rows are dead: their space becomes the slabs
+  if (!active) return;                          // no barrier below
+  const float inv_keep = drop ? 1.f / (1.f - p.p_drop) : 1.f;
+  const float sl = p.scale * AT_LOG2E;
+  unsigned char* slab = Ps + wave * 32 * AT_SP;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int r = acc_row(q, h);                         // key row inside the block = bit index
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      lq[j] = lse[32 * j + l31];
-      dq_[j] = delta[32 * j + l31] + delta[128 + 32 * j + l31];
-      kwq[j] = keep[(32 * j + l31) * 4 + wave];          // keys of this wave's block, of query 32 j + l31
-    }
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const int r = acc_row(q, h);                       // key row inside the block = bit index
-      const float kbk = kb[row0 + r];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(acc[j][q], sl, kbk) - lq[j]);
-        const bool keepb = (kwq[j] >> r) & 1u;
-        *reinterpret_cast<unsigned short*>(slab + r * AT_SP + (32 * j + l31) * 2) = f2bf(keepb ? pr * inv_keep : 0.f);
-        const float dp = keepb ? acc2[j][q] * inv_keep : 0.f;
-        acc2[j][q] = pr * (dp - dq_[j]) * p.scale;        // dS^T, kept for the second product
-      }
+      const float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(acc[j][q], sl, kbk16[q]) - lq[j]);
+      const bool keepb = (kwq[j] >> r) & 1u;
+      *reinterpret_cast<unsigned short*>(slab + r * AT_SP + (32 * j + l31) * 2) = f2bf(keepb ? pr * inv_keep : 0.f);
+      const float dp = keepb ? acc2[j][q] * inv_keep : 0.f;
+      acc2[j][q] = pr * (dp - dq_[j]) * p.scale;          // dS^T, kept for the second product
     }
   }
   zero16(out[0]); zero16(out[1]);
   gemm_tokens(out, slab, Gt, tp, kt, l31, h);             // dV = Pd^T dO
   {
-    // stash dV in registers while the slab is reused: write dS^T, dK, then both results go out through the slab
     f32x16 dvv[2] = {out[0], out[1]};
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
       const int r = acc_row(q, h);
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-        *reinterpret_cast<unsigned short*>(slab + r * AT_SP + (32 * j + l31) * 2) = f2bf(acc2[j][q]);
+      for (int j = 0; j < 4; ++j) *reinterpret_cast<unsigned short*>(slab + r * AT_SP + (32 * j + l31) * 2) = f2bf(acc2[j][q]);
     }
     zero16(out[0]); zero16(out[1]);
     gemm_tokens(out, slab, Qt, tp, kt, l31, h);           // dK = dS^T Q
@@ -370,7 +437,9 @@ __global__ void __launch_bounds__(AT_NT) k_attn_bwd(AttnParams p) {
 // bytes per row of the token-contiguous (transposed) LDS operands
 int attn_tp(int L) { return 2 * ((L + 15) & ~15) + 16; }
 size_t attn_lds_fwd(int L) { return (size_t)2 * 128 * AT_RP + (size_t)64 * attn_tp(L) + 512; }   // slabs alias Q / K: 128 AT_SP <= 256 AT_RP
-size_t attn_lds_bwd(int L) { return (size_t)4 * 128 * AT_RP + (size_t)3 * 64 * attn_tp(L) + (size_t)128 * AT_SP + 4 * 512 + 2048; }
+size_t attn_lds_bwd_q(int L) { return (size_t)2 * 128 * AT_RP + (size_t)64 * attn_tp(L) + 3 * 512 + 2048; }
+size_t attn_lds_bwd_kv(int L) { return (size_t)2 * 128 * AT_RP + (size_t)2 * 64 * attn_tp(L) + 4 * 512 + 2048; }
+size_t attn_lds_bwd(int L) { return attn_lds_bwd_kv(L) > attn_lds_bwd_q(L) ? attn_lds_bwd_kv(L) : attn_lds_bwd_q(L); }
 
 int attn_fill(AttnParams& p, const void* q, const void* k, const void* v, const unsigned char* key_mask, int B, int nh, int L, int ld,
               int ld_o, float scale, float p_drop, unsigned long long seed, unsigned long long offset) {
@@ -417,9 +486,12 @@ extern "C" int glr_attn_bwd(const void* q, const void* k, const void* v, const v
   if (!o || !d_o || !lse || !dq || !dk || !dv || (p_drop > 0.f && !keep) || L > glr_attn_max_tokens(1)) return GLR_EINVAL;
   p.o = (unsigned short*)const_cast<void*>(o); p.d_o = (const unsigned short*)d_o; p.lse = const_cast<float*>(lse);
   p.keep = const_cast<unsigned*>(keep); p.dq = (unsigned short*)dq; p.dk = (unsigned short*)dk; p.dv = (unsigned short*)dv;
-  const int lds = (int)attn_lds_bwd(L);
-  if (hipFuncSetAttribute((const void*)k_attn_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return GLR_ELAUNCH;
-  hipLaunchKernelGGL(k_attn_bwd, dim3(B * n_heads), dim3(AT_NT), lds, (hipStream_t)stream, p);
+  const int lds_q = (int)attn_lds_bwd_q(L), lds_kv = (int)attn_lds_bwd_kv(L);
+  if (hipFuncSetAttribute((const void*)k_attn_bwd_q, hipFuncAttributeMaxDynamicSharedMemorySize, lds_q) != hipSuccess) return GLR_ELAUNCH;
+  if (hipFuncSetAttribute((const void*)k_attn_bwd_kv, hipFuncAttributeMaxDynamicSharedMemorySize, lds_kv) != hipSuccess) return GLR_ELAUNCH;
+  hipLaunchKernelGGL(k_attn_bwd_q, dim3(B * n_heads), dim3(AT_NT), lds_q, (hipStream_t)stream, p);
+  GLR_CHECK_LAUNCH();
+  hipLaunchKernelGGL(k_attn_bwd_kv, dim3(B * n_heads), dim3(AT_NT), lds_kv, (hipStream_t)stream, p);
   GLR_CHECK_LAUNCH();
   return GLR_OK;
 }

@@ -4,7 +4,7 @@
 
 `self_attention(q, k, v, key_mask, n_heads, p, training)` takes the [B, L, H] outputs of the query / key / value Linears
 as they are and returns the context in the same layout.  The kernels cover what the training step runs: GPU, bf16
-(autocast), head size 64, L <= 112 tokens; every other case is torch's scaled_dot_product_attention on the same
+(autocast), head size 64, L <= 128 tokens; every other case is torch's scaled_dot_product_attention on the same
 tensors.  Dropout bits: Philox4x32-10 keyed by the CUDA generator's seed and offset (reproducible under
 torch.manual_seed; not the same stream as torch's own dropout).  `GLR_FUSED_ATTN=0` switches the kernels off."""
 

@@ -387,8 +387,8 @@ int glr_drop_add_ln_bwd(const float* dy32, const void* dy16, const void* h16, co
  * three column blocks are passed as q, k, v); key_mask uint8 [B, L] (nonzero = attend) or NULL; lse fp32 [B * n_heads, 128] (row
  * log-sum-exp, saved for the backward); keep uint32 [B * n_heads, 128, 4]: dropout keep bits, key 32 j + i of query
  * row r = bit i of word (r, j) (NULL when p_drop == 0).  seed / offset: Philox4x32-10 key / counter prefix.
- * One workgroup per (sentence, head); glr_attn_max_tokens(backward) = largest L whose operands fit the 160 KB LDS
- * (128 forward, 112 backward).  Replaces a library flash-attention call that spends 95 + 390 us per layer here.
+ * One workgroup per (sentence, head) and pass (the backward runs a query pass and a key pass); glr_attn_max_tokens(
+ * backward) = largest supported L (128).  Replaces a library flash-attention call that spends 95 + 390 us per layer here.
  */
 int glr_attn_max_tokens(int backward);
 int glr_attn_fwd(const void* q, const void* k, const void* v, const uint8_t* key_mask, int B, int n_heads, int L, int ld,

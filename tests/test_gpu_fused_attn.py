@@ -32,7 +32,7 @@ def _decode_keep(keep, B, nh, L):
 
 
 @pytest.mark.parametrize("B,nh,L,p,ragged", [(3, 12, 97, 0.0, True), (2, 12, 97, 0.1, True), (2, 4, 40, 0.3, False),
-                                              (2, 2, 112, 0.1, True), (3, 1, 16, 0.0, False), (2, 3, 1, 0.0, False),
+                                              (2, 2, 112, 0.1, True), (2, 2, 128, 0.1, True), (3, 1, 16, 0.0, False), (2, 3, 1, 0.0, False),
                                               (2, 2, 33, 0.2, True)])
 def test_attention_matches_torch(B, nh, L, p, ragged):
     from gloria import _native as N
