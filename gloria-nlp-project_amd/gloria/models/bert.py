@@ -38,8 +38,9 @@ class BertEmbeddings(nn.Module):
         L = ids.shape[1]
         if token_type is None:
             token_type = torch.zeros_like(ids)
-        x = self.word_embeddings(ids) + self.token_type_embeddings(token_type) + \
-            self.position_embeddings(self.position_ids[:, :L])
+        # positions are arange(L) (position_ids[:, :L]): the first L rows of the table, broadcast over the batch - the
+        # backward is then a plain sum over the batch instead of the sort-and-scatter of an embedding lookup (0.55 ms)
+        x = self.word_embeddings(ids) + self.token_type_embeddings(token_type) + self.position_embeddings.weight[:L]
         return self.dropout(self.LayerNorm(x))
 
 

@@ -200,3 +200,32 @@ def test_plan_rowflags_match_python_restatement():
         assert owners == n                      # exactly one owner run per sentence
         checked += 1
     assert checked >= 5
+
+
+def test_planner_caps_sentences_per_tile_when_that_saves_work_items():
+    """glr_plan_tiles with pairing in view: every sentence keeps cap_lens consecutive slots inside one tile, pairs hold
+    at most 8 sentences, ordinary tiles are contiguous behind the multi-tile runs, and at the bench's caption lengths
+    no tile is left unpaired (plain first fit leaves 6 .. 7 crowded tiles that cannot pair)."""
+    from gloria import _native as N
+    for seed in (1234, 1, 2):
+        rng = np.random.default_rng(seed)
+        lens = (np.sort(rng.integers(4, 40, size=256))[::-1] + 1).astype(int)
+        p = N.TilePlan(lens, "cpu")
+        assert p.n_single <= 1 and p.n_pair >= 46
+        slot0 = p.sent_slot0.numpy() if hasattr(p.sent_slot0, "numpy") else np.asarray(p.sent_slot0)
+        used = np.zeros(p.n_tiles * 64, dtype=int)
+        for i, n in enumerate(lens):
+            assert slot0[i] // 64 == (slot0[i] + n - 1) // 64           # inside one tile
+            used[slot0[i]:slot0[i] + n] += 1
+        assert used.max() == 1 and used.sum() == lens.sum()
+        tf, pairs = p.tile_first.numpy(), p.pair_tile.numpy()
+        for t in pairs[:p.n_pair]:
+            assert tf[t + 2] - tf[t] <= N.MAX_PAIR_SEG
+        # without pairing (the fp32 mode's 32-word tiles) the planner is plain first fit: no more tiles than needed + slack
+        q = N.TilePlan(lens, "cpu", capacity=32, allow_pairs=False)
+        assert q.n_pair == 0 and q.n_tiles * 32 >= lens.sum()
+    mixed = np.random.default_rng(5).integers(1, 300, size=40)
+    p = N.TilePlan(mixed, "cpu")
+    nsub = p.tile_nsub.numpy()
+    first_ordinary = int(np.argmax(nsub == 0)) if (nsub == 0).any() else len(nsub)
+    assert (nsub[first_ordinary:] == 0).all()                            # ordinary tiles are contiguous at the end
