@@ -5,12 +5,32 @@ Linear(2048, 768) / bias-free Conv1x1(1024, 768) embedders (:20-28, :52-65).
 Parameter names equal the reference's (`model.*`, `global_embedder.*`, `local_embedder.weight`).
 """
 
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .. import _native as N
 from . import cnn_backbones
 from .fused_bn import fused_bn_act
+
+
+_FUSED_RESIZE = os.environ.get("GLR_FUSED_RESIZE", "1") != "0"
+
+
+def _resize_299(x):
+    """F.interpolate(x, (299, 299), bilinear, align_corners=True) (vision_model.py:68).  Under bf16 autocast on the GPU
+    the resize, the channels-last copy and the cast in front of conv1 are one HIP pass (glr_upsample_bilinear_cl)."""
+    if (_FUSED_RESIZE and x.is_cuda and x.dtype == torch.float32 and not x.requires_grad and torch.is_autocast_enabled("cuda")
+            and torch.get_autocast_dtype("cuda") == torch.bfloat16):
+        B, C, H, W = x.shape
+        y = torch.empty((B, C, 299, 299), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
+        sn, sc, sh, sw = x.stride()
+        N.check(N.lib().glr_upsample_bilinear_cl(N.ptr(x), sn, sc, sh, sw, B, C, H, W, 299, 299, N.ptr(y), N.stream()),
+                "glr_upsample_bilinear_cl")
+        return y
+    return F.interpolate(x, size=(299, 299), mode="bilinear", align_corners=True)
 
 
 class ImageEncoder(nn.Module):
@@ -45,7 +65,7 @@ class ImageEncoder(nn.Module):
         return global_emb, local_emb
 
     def resnet_forward(self, x, extract_features=False):
-        x = F.interpolate(x, size=(299, 299), mode="bilinear", align_corners=True)
+        x = _resize_299(x)
         m = self.model
         x = m.maxpool(fused_bn_act(m.bn1, m.conv1(x)))         # (B, 64, 75, 75)
         x = m.layer1(x)                                  # (B, 256, 75, 75)

@@ -336,6 +336,12 @@ int glr_topk_desc(const float* x, int rows, long long n, int k, int64_t* idx, fl
 int glr_threshold_counts(const float* pred, const uint8_t* target, const float* thr, int rows, long long n,
                          uint64_t* out, void* stream);
 
+/* Input resize of the image encoder: F.interpolate(x, (Ho, Wo), mode="bilinear", align_corners=True)
+ * (gloria/models/vision_model.py:68) fused with the layout copy and the bf16 cast autocast puts in front of conv1.
+ * x fp32 [B, C, Hi, Wi] with element strides (sn, sc, sh, sw) (NCHW or channels-last); y bf16 [B, Ho, Wo, C]. */
+int glr_upsample_bilinear_cl(const float* x, long long sn, long long sc, long long sh, long long sw, int B, int C, int Hi,
+                             int Wi, int Ho, int Wo, void* y, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Fused training-mode BatchNorm2d (+ residual add) (+ ReLU) on channels-last bf16 activations: the 53 normalisation
  * sites of the ResNet-50 image encoder (reference: torchvision resnet50 through

@@ -69,3 +69,22 @@ def test_fused_bn_is_deterministic_and_falls_back(monkeypatch):
     bn.train()
     f = FB.fused_bn_act(bn, xf)
     assert f.dtype == torch.float32
+
+
+@pytest.mark.parametrize("channels_last", [False, True])
+def test_input_resize_matches_interpolate(channels_last):
+    """glr_upsample_bilinear_cl (resize + channels-last + bf16 in one pass) against F.interpolate(align_corners=True)
+    followed by the cast autocast applies in front of conv1."""
+    from gloria.models import vision_model as VM
+    x = torch.rand(5, 3, 224, 224, device=DEV) * 2 - 1
+    if channels_last:
+        x = x.contiguous(memory_format=torch.channels_last)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y = VM._resize_299(x)
+    assert y.dtype == torch.bfloat16 and y.shape == (5, 3, 299, 299) and y.is_contiguous(memory_format=torch.channels_last)
+    ref = torch.nn.functional.interpolate(x, size=(299, 299), mode="bilinear", align_corners=True)
+    # bf16 rounding of values in [-1, 1]: one ulp = 2^-8 relative where the two fp32 results straddle a rounding boundary
+    np.testing.assert_allclose(y.float().cpu().numpy(), ref.bfloat16().float().cpu().numpy(), atol=2 ** -8, rtol=0)
+    assert (y.float() - ref).abs().max().item() < 2 ** -8
+    z = VM._resize_299(x)                                # outside autocast: torch's operator
+    assert z.dtype == torch.float32
