@@ -11,7 +11,7 @@ import warnings
 import torch
 import torch.nn as nn
 
-from .fused_bn import fused_bn_act
+from .fused_bn import fused_bn_act, fused_maxpool
 
 
 class Identity(nn.Module):
@@ -77,7 +77,7 @@ class ResNet50(nn.Module):
         return nn.Sequential(*layers)
 
     def forward(self, x):
-        x = self.maxpool(fused_bn_act(self.bn1, self.conv1(x)))
+        x = fused_maxpool(self.maxpool, fused_bn_act(self.bn1, self.conv1(x)))
         x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
         return self.fc(torch.flatten(self.avgpool(x), 1))
 

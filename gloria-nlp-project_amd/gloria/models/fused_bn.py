@@ -83,3 +83,37 @@ def fused_bn_act(bn, x, residual=None, relu=True):
     if residual is not None:
         out = out + residual
     return F.relu(out) if relu else out
+
+
+class _MaxPool3s2(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        n, c, h, w = x.shape
+        ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+        y = torch.empty((n, c, ho, wo), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+        idx = torch.empty((n, ho, wo, c), dtype=torch.uint8, device=x.device)
+        N.check(N.lib().glr_maxpool3s2_fwd(N.ptr(x), n, h, w, c, N.ptr(y), N.ptr(idx), N.stream()), "glr_maxpool3s2_fwd")
+        ctx.save_for_backward(idx)
+        ctx.shape = (n, c, h, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (idx,) = ctx.saved_tensors
+        n, c, h, w = ctx.shape
+        if dy.dtype != torch.bfloat16 or not dy.is_contiguous(memory_format=torch.channels_last):
+            dy = dy.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        dx = torch.empty((n, c, h, w), dtype=torch.bfloat16, device=dy.device, memory_format=torch.channels_last)
+        N.check(N.lib().glr_maxpool3s2_bwd(N.ptr(dy), N.ptr(idx), n, h, w, c, N.ptr(dx), N.stream()), "glr_maxpool3s2_bwd")
+        return dx
+
+
+def fused_maxpool(pool, x):
+    """nn.MaxPool2d(3, stride=2, padding=1) `pool` on x; channels-last bf16 on the GPU runs the one-byte-argmax kernels."""
+    def _is(v, k):
+        return v == k or v == (k, k)
+    if (ENABLED and x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4 and x.shape[1] % 8 == 0
+            and x.is_contiguous(memory_format=torch.channels_last) and _is(pool.kernel_size, 3) and _is(pool.stride, 2)
+            and _is(pool.padding, 1) and _is(pool.dilation, 1) and not pool.ceil_mode and not pool.return_indices):
+        return _MaxPool3s2.apply(x)
+    return pool(x)

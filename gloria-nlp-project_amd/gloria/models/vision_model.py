@@ -13,7 +13,7 @@ import torch.nn.functional as F
 
 from .. import _native as N
 from . import cnn_backbones
-from .fused_bn import fused_bn_act
+from .fused_bn import fused_bn_act, fused_maxpool
 
 
 _FUSED_RESIZE = os.environ.get("GLR_FUSED_RESIZE", "1") != "0"
@@ -67,7 +67,7 @@ class ImageEncoder(nn.Module):
     def resnet_forward(self, x, extract_features=False):
         x = _resize_299(x)
         m = self.model
-        x = m.maxpool(fused_bn_act(m.bn1, m.conv1(x)))         # (B, 64, 75, 75)
+        x = fused_maxpool(m.maxpool, fused_bn_act(m.bn1, m.conv1(x)))         # (B, 64, 75, 75)
         x = m.layer1(x)                                  # (B, 256, 75, 75)
         x = m.layer2(x)                                  # (B, 512, 38, 38)
         x = m.layer3(x)                                  # (B, 1024, 19, 19)

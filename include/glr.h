@@ -336,6 +336,12 @@ int glr_topk_desc(const float* x, int rows, long long n, int k, int64_t* idx, fl
 int glr_threshold_counts(const float* pred, const uint8_t* target, const float* thr, int rows, long long n,
                          uint64_t* out, void* stream);
 
+/* MaxPool2d(kernel 3, stride 2, padding 1) of the ResNet stem (torchvision resnet50 through cnn_backbones.py:31-35) on
+ * channels-last bf16: x [B, H, W, C] -> y [B, Ho, Wo, C], Ho = (H - 1) / 2 + 1; idx uint8 [B, Ho, Wo, C] = position 0..8 of
+ * the first maximum inside its window (instead of torch's int64 argmax); the backward gathers (no zero fill, no scatter). */
+int glr_maxpool3s2_fwd(const void* x, int B, int H, int W, int C, void* y, uint8_t* idx, void* stream);
+int glr_maxpool3s2_bwd(const void* dy, const uint8_t* idx, int B, int H, int W, int C, void* dx, void* stream);
+
 /* Input resize of the image encoder: F.interpolate(x, (Ho, Wo), mode="bilinear", align_corners=True)
  * (gloria/models/vision_model.py:68) fused with the layout copy and the bf16 cast autocast puts in front of conv1.
  * x fp32 [B, C, Hi, Wi] with element strides (sn, sc, sh, sw) (NCHW or channels-last); y bf16 [B, Ho, Wo, C]. */

@@ -88,3 +88,24 @@ def test_input_resize_matches_interpolate(channels_last):
     assert (y.float() - ref).abs().max().item() < 2 ** -8
     z = VM._resize_299(x)                                # outside autocast: torch's operator
     assert z.dtype == torch.float32
+
+
+@pytest.mark.parametrize("n,c,h,w", [(3, 64, 150, 150), (2, 8, 7, 9), (1, 16, 2, 2), (2, 32, 33, 17)])
+def test_maxpool_matches_torch_including_ties(n, c, h, w):
+    """One-byte-argmax max pooling (3, stride 2, padding 1) against torch's on ReLU-ed input (most windows hold tied
+    zeros: the gradient must go to the FIRST maximum in scan order, as torch's does)."""
+    from gloria.models import fused_bn as FB
+    g = torch.Generator().manual_seed(n * 10 + c)
+    x = torch.relu(torch.randn(n, c, h, w, generator=g)).to(DEV).bfloat16().contiguous(memory_format=torch.channels_last)
+    pool = torch.nn.MaxPool2d(3, stride=2, padding=1)
+    xa = x.clone().requires_grad_(True)
+    ya = FB.fused_maxpool(pool, xa)
+    xb = x.clone().requires_grad_(True)
+    yb = pool(xb)
+    assert ya.shape == yb.shape and ya.is_contiguous(memory_format=torch.channels_last)
+    assert torch.equal(ya, yb)
+    dy = torch.randn(yb.shape, generator=g).to(DEV).bfloat16().contiguous(memory_format=torch.channels_last)
+    ya.backward(dy)
+    yb.backward(dy)
+    np.testing.assert_allclose(xa.grad.float().cpu().numpy(), xb.grad.float().cpu().numpy(), rtol=1e-2, atol=1e-2)
+    assert torch.equal(xa.grad != 0, xb.grad != 0)          # identical routing
