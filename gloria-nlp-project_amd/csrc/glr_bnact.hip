@@ -50,7 +50,7 @@ __global__ void __launch_bounds__(BN_NT) k_bn_reduce(const unsigned short* __res
                                                      const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, long long R, int C, int relu,
                                                      int n_part, float* __restrict__ part,
-                                                     unsigned short* __restrict__ dz_out) {
+                                                     unsigned short* __restrict__ dz_out, const unsigned short* __restrict__ dy2) {
   constexpr int UN = MODE == 0 ? 8 : 4;
   const int cg_per_blk = min(C / 8, 32), rl_per_blk = BN_NT / cg_per_blk;
   const int cg = blockIdx.x * cg_per_blk + threadIdx.x % cg_per_blk, rl = threadIdx.x / cg_per_blk;
@@ -70,7 +70,8 @@ __global__ void __launch_bounds__(BN_NT) k_bn_reduce(const unsigned short* __res
   const long long r_end = R;
   const long long slab = (long long)UN * rl_per_blk;
   for (long long r = (long long)blockIdx.y * slab + rl; r < r_end; r += slab * gridDim.y) {
-    uint4 xr[UN], dr[UN], yr[UN];
+    uint4 xr[UN], dr[UN], yr[UN], d2[UN];
+    const bool two = MODE == 1 && RESID && dy2 != nullptr;     // the gradient arrives as two tensors (main + skip consumer)
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
       const long long ru = r + (long long)u * rl_per_blk;
@@ -78,6 +79,7 @@ __global__ void __launch_bounds__(BN_NT) k_bn_reduce(const unsigned short* __res
         xr[u] = ldv(x + ru * C + c0);
         if (MODE == 1) dr[u] = ldv(dy + ru * C + c0);
         if (MODE == 1 && RESID) yr[u] = ldv(y + ru * C + c0);
+        if (two) d2[u] = ldv(dy2 + ru * C + c0);
       }
     }
 #pragma unroll
@@ -93,6 +95,12 @@ __global__ void __launch_bounds__(BN_NT) k_bn_reduce(const unsigned short* __res
           float dv[8], yv[8], dzv[8];
           unpack8(dr[u], dv);
           if (RESID) unpack8(yr[u], yv);
+          if (two) {
+            float d2v[8];
+            unpack8(d2[u], d2v);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) dv[i] += d2v[i];
+          }
 #pragma unroll
           for (int i = 0; i < 8; ++i) {
             const bool on = !relu || (RESID ? yv[i] > 0.f : __builtin_fmaf(xv[i], sc[i], sh[i]) > 0.f);
@@ -306,7 +314,7 @@ extern "C" int glr_bn_act_fwd(const void* x, const void* residual, const float* 
   static const int res0 = bn_resident((const void*)k_bn_reduce<0, false>);
   const BnPlan pl = bn_plan(R, C, res0, 8);
   hipLaunchKernelGGL((k_bn_reduce<0, false>), dim3(pl.col_blocks, pl.n_part), dim3(BN_NT), 0, st, (const unsigned short*)x,
-                     nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, R, C, 0, pl.n_part, workspace, nullptr);
+                     nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, R, C, 0, pl.n_part, workspace, nullptr, nullptr);
   GLR_CHECK_LAUNCH();
   hipLaunchKernelGGL((k_bn_finish<true>), dim3((C + 3) / 4), dim3(BN_NT), 0, st, workspace, pl.n_part, C, R, eps, momentum,
                      mean, invstd, run_mean, run_var, num_batches_tracked);
@@ -325,11 +333,11 @@ extern "C" int glr_bn_act_fwd(const void* x, const void* residual, const float* 
 
 // out4c = [dgamma | dbeta | mean(dz) | mean(dz xhat)], 4*C floats.  has_residual: `y` (the forward's output) gives
 // the ReLU mask and `dres` receives the masked gradient (the skip connection's gradient).
-extern "C" int glr_bn_act_bwd(const void* x, const void* dy, const void* y, const float* gamma, const float* beta,
+extern "C" int glr_bn_act_bwd(const void* x, const void* dy, const void* dy2, const void* y, const float* gamma, const float* beta,
                               const float* mean, const float* invstd, long long R, int C, int relu, int has_residual,
                               float* workspace, float* out4c, void* dx, void* dres, void* stream) {
   if (!x || !dy || !gamma || !beta || !mean || !invstd || !workspace || !out4c || !dx || !bn_shape_ok(R, C) ||
-      (has_residual && (!y || !dres)))
+      (has_residual && (!y || !dres)) || (dy2 && !has_residual))
     return GLR_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   static const int res1 = bn_resident((const void*)k_bn_reduce<1, false>);
@@ -339,10 +347,10 @@ extern "C" int glr_bn_act_bwd(const void* x, const void* dy, const void* y, cons
   if (has_residual)
     hipLaunchKernelGGL((k_bn_reduce<1, true>), rgrid, dim3(BN_NT), 0, st, (const unsigned short*)x, (const unsigned short*)dy,
                        (const unsigned short*)y, mean, invstd, gamma, beta, R, C, relu, pl.n_part, workspace,
-                       (unsigned short*)dres);
+                       (unsigned short*)dres, (const unsigned short*)dy2);
   else
     hipLaunchKernelGGL((k_bn_reduce<1, false>), rgrid, dim3(BN_NT), 0, st, (const unsigned short*)x, (const unsigned short*)dy,
-                       nullptr, mean, invstd, gamma, beta, R, C, relu, pl.n_part, workspace, nullptr);
+                       nullptr, mean, invstd, gamma, beta, R, C, relu, pl.n_part, workspace, nullptr, nullptr);
   GLR_CHECK_LAUNCH();
   hipLaunchKernelGGL((k_bn_finish<false>), dim3((C + 3) / 4), dim3(BN_NT), 0, st, workspace, pl.n_part, C, R, 0.f, 0.f, out4c,
                      out4c + C, out4c + 2 * C, out4c + 3 * C, (long long*)nullptr);

@@ -11,7 +11,7 @@ import warnings
 import torch
 import torch.nn as nn
 
-from .fused_bn import fused_bn_act, fused_maxpool
+from .fused_bn import SkipPair, fused_bn_act, fused_maxpool
 
 
 class Identity(nn.Module):
@@ -33,16 +33,30 @@ class Bottleneck(nn.Module):
         self.relu = nn.ReLU(inplace=True)
         self.downsample = downsample
 
-    def forward(self, x):
+    def forward(self, x, fork=False):
         # BatchNorm + ReLU (+ the skip connection) run as one fused HIP pass pair per direction on channels-last bf16
-        # (gloria/models/fused_bn.py); same modules / parameters / buffers as torchvision's bottleneck
+        # (gloria/models/fused_bn.py); same modules / parameters / buffers as torchvision's bottleneck.
+        # x may be a SkipPair from the previous block of the stage; fork=True asks for one for the next block.
         identity = x
+        if isinstance(x, SkipPair):
+            x, identity = x.main, x.skip
         out = fused_bn_act(self.bn1, self.conv1(x))
         out = fused_bn_act(self.bn2, self.conv2(out))
         out = self.conv3(out)
         if self.downsample is not None:
-            identity = fused_bn_act(self.downsample[1], self.downsample[0](x), relu=False)
-        return fused_bn_act(self.bn3, out, residual=identity)
+            identity = fused_bn_act(self.downsample[1], self.downsample[0](identity), relu=False)
+        return fused_bn_act(self.bn3, out, residual=identity, fork=fork)
+
+
+class _Stage(nn.Sequential):
+    """nn.Sequential of bottlenecks (same child names); inside the stage a block hands its output to the next as a
+    SkipPair, the stage itself returns a tensor."""
+
+    def forward(self, x):
+        blocks = list(self)
+        for i, blk in enumerate(blocks):
+            x = blk(x, fork=i + 1 < len(blocks))
+        return x
 
 
 class ResNet50(nn.Module):
@@ -74,7 +88,7 @@ class ResNet50(nn.Module):
         layers = [Bottleneck(self.inplanes, planes, stride, downsample)]
         self.inplanes = planes * 4
         layers += [Bottleneck(self.inplanes, planes) for _ in range(1, blocks)]
-        return nn.Sequential(*layers)
+        return _Stage(*layers)
 
     def forward(self, x):
         x = fused_maxpool(self.maxpool, fused_bn_act(self.bn1, self.conv1(x)))

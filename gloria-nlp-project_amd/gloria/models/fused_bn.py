@@ -30,7 +30,7 @@ def _workspace(dev, n):
 
 class _BNAct(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, residual, weight, bias, run_mean, run_var, nbt, eps, momentum, relu):
+    def forward(ctx, x, residual, weight, bias, run_mean, run_var, nbt, eps, momentum, relu, fork):
         L = N.lib()
         n, c, h, w = x.shape
         R = n * h * w
@@ -43,25 +43,38 @@ class _BNAct(torch.autograd.Function):
                                  N.ptr(ws), N.ptr(y), N.stream()), "glr_bn_act_fwd")
         ctx.save_for_backward(x, y if residual is not None else None, weight, bias, stats)
         ctx.relu, ctx.has_res = bool(relu), residual is not None
+        if fork:
+            # a second handle on the same storage for the skip consumer of the next block: the two gradients then
+            # arrive separately and are added while the backward kernel reads them (autograd would run an add kernel)
+            ctx.set_materialize_grads(False)
+            return y, y.detach()
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dy2=None):
         x, y, weight, bias, stats = ctx.saved_tensors
+        if dy is None:
+            dy, dy2 = dy2, None
+        if dy is None:
+            return (None,) * 11
         L = N.lib()
         n, c, h, w = x.shape
         R = n * h * w
         dev = x.device
         if dy.dtype != torch.bfloat16 or not dy.is_contiguous(memory_format=torch.channels_last):
             dy = dy.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        if dy2 is not None and (dy2.dtype != torch.bfloat16 or not dy2.is_contiguous(memory_format=torch.channels_last)):
+            dy2 = dy2.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        if dy2 is not None and not ctx.has_res:
+            dy, dy2 = dy + dy2, None
         dx = torch.empty_like(x)
         dres = torch.empty_like(x) if ctx.has_res else None
         out = torch.empty(4, c, dtype=torch.float32, device=dev)
         ws = _workspace(dev, L.glr_bn_workspace_floats(R, c))
-        N.check(L.glr_bn_act_bwd(N.ptr(x), N.ptr(dy), N.ptr(y), N.ptr(weight), N.ptr(bias), stats.data_ptr(), stats.data_ptr() + 4 * c,
+        N.check(L.glr_bn_act_bwd(N.ptr(x), N.ptr(dy), N.ptr(dy2), N.ptr(y), N.ptr(weight), N.ptr(bias), stats.data_ptr(), stats.data_ptr() + 4 * c,
                                  R, c, 1 if ctx.relu else 0, 1 if ctx.has_res else 0, N.ptr(ws), N.ptr(out), N.ptr(dx),
                                  N.ptr(dres), N.stream()), "glr_bn_act_bwd")
-        return dx, dres, out[0], out[1], None, None, None, None, None, None
+        return dx, dres, out[0], out[1], None, None, None, None, None, None, None
 
 
 def _fusable(bn, x, residual):
@@ -74,11 +87,23 @@ def _fusable(bn, x, residual):
                                       and residual.is_contiguous(memory_format=torch.channels_last))))
 
 
-def fused_bn_act(bn, x, residual=None, relu=True):
-    """relu?(bn(x) (+ residual)) with nn.BatchNorm2d `bn`'s parameters and running statistics."""
+class SkipPair:
+    """(main, skip): two handles on ONE block output - the next block's convolution reads `main`, its skip connection
+    `skip` - so that the two gradients reach the producing kernel separately (no autograd add in between)."""
+    __slots__ = ("main", "skip")
+
+    def __init__(self, main, skip):
+        self.main, self.skip = main, skip
+
+
+def fused_bn_act(bn, x, residual=None, relu=True, fork=False):
+    """relu?(bn(x) (+ residual)) with nn.BatchNorm2d `bn`'s parameters and running statistics.  fork=True (fused path,
+    with a residual): returns a SkipPair instead of a tensor."""
     if _fusable(bn, x, residual):
-        return _BNAct.apply(x, residual, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked, bn.eps,
-                            bn.momentum, relu)
+        fork = bool(fork and residual is not None and torch.is_grad_enabled())
+        out = _BNAct.apply(x, residual, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked, bn.eps,
+                           bn.momentum, relu, fork)
+        return SkipPair(*out) if fork else out
     out = bn(x)
     if residual is not None:
         out = out + residual

@@ -358,7 +358,8 @@ int glr_upsample_bilinear_cl(const float* x, long long sn, long long sc, long lo
  *         (int64 scalar, NULL = none) is incremented by the same launch;
  *         y = relu?( (x - mean) invstd gamma + beta (+ residual) )
  *   bwd   dx; out4c = [dgamma | dbeta | 2C floats of scratch]; with a residual also dres = dy * [y > 0] (the
- *         gradient of the skip branch), y = the forward's output
+ *         gradient of the skip branch), y = the forward's output; dy2 (optional, with a residual only): a second
+ *         gradient tensor of y, added to dy while it is read (the next block's main and skip consumers)
  *   workspace: glr_bn_workspace_floats(R, C) floats (0 = shape not supported).
  * HBM-bound: 3 (4) tensor passes forward, 5 (7) backward; fixed-order two-level reductions (bitwise reproducible).
  */
@@ -366,7 +367,7 @@ int glr_bn_workspace_floats(long long R, int C);
 int glr_bn_act_fwd(const void* x, const void* residual, const float* gamma, const float* beta, long long R, int C,
                    float eps, float momentum, int relu, float* run_mean, float* run_var, long long* num_batches_tracked,
                    float* mean, float* invstd, float* workspace, void* y, void* stream);
-int glr_bn_act_bwd(const void* x, const void* dy, const void* y, const float* gamma, const float* beta, const float* mean,
+int glr_bn_act_bwd(const void* x, const void* dy, const void* dy2, const void* y, const float* gamma, const float* beta, const float* mean,
                    const float* invstd, long long R, int C, int relu, int has_residual, float* workspace, float* out4c,
                    void* dx, void* dres, void* stream);
 

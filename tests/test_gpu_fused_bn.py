@@ -109,3 +109,71 @@ def test_maxpool_matches_torch_including_ties(n, c, h, w):
     yb.backward(dy)
     np.testing.assert_allclose(xa.grad.float().cpu().numpy(), xb.grad.float().cpu().numpy(), rtol=1e-2, atol=1e-2)
     assert torch.equal(xa.grad != 0, xb.grad != 0)          # identical routing
+
+
+def test_forked_output_gradients_are_summed_in_the_kernel():
+    """fused_bn_act(..., fork=True) returns two handles on one output; the backward kernel adds their two gradients
+    while reading them.  Against the single-output op fed with the (fp32) sum."""
+    from gloria.models import fused_bn as FB
+    g = torch.Generator().manual_seed(5)
+    n, c, h, w = 6, 256, 19, 19
+    cl = lambda t: t.to(DEV).bfloat16().contiguous(memory_format=torch.channels_last)
+    x, r = cl(torch.randn(n, c, h, w, generator=g)), cl(torch.randn(n, c, h, w, generator=g))
+    ga, gb = cl(torch.randn(n, c, h, w, generator=g)), cl(torch.randn(n, c, h, w, generator=g))
+    bn = torch.nn.BatchNorm2d(c).to(DEV).train()
+    res = {}
+    for fork in (True, False):
+        xa, ra = x.clone().requires_grad_(True), r.clone().requires_grad_(True)
+        bn.zero_grad()
+        out = FB.fused_bn_act(bn, xa, ra, True, fork=fork)
+        if fork:
+            assert isinstance(out, FB.SkipPair) and out.main.data_ptr() == out.skip.data_ptr()
+            ((out.main.float() * ga.float()).sum() + (out.skip.float() * gb.float()).sum()).backward()
+            y = out.main
+        else:
+            (out.float() * (ga.float() + gb.float())).sum().backward()
+            y = out
+        res[fork] = (y.detach().clone(), xa.grad.float(), ra.grad.float(), bn.weight.grad.clone(), bn.bias.grad.clone())
+    assert torch.equal(res[True][0], res[False][0])
+    for a, b in zip(res[True][1:], res[False][1:]):
+        rel = float((a - b).norm() / b.norm())
+        assert rel < 1e-2, rel
+    # only the skip handle used: the other gradient arrives as None
+    xa, ra = x.clone().requires_grad_(True), r.clone().requires_grad_(True)
+    out = FB.fused_bn_act(bn, xa, ra, True, fork=True)
+    (out.skip.float() * gb.float()).sum().backward()
+    assert torch.isfinite(xa.grad.float()).all() and float(xa.grad.float().abs().sum()) > 0
+
+
+def test_resnet_with_forked_block_outputs_trains(monkeypatch):
+    """ResNet-50 in training mode under bf16 autocast, fused kernels with block outputs handed on as (main, skip) pairs
+    against the same kernels with autograd's own add in between: same parameters receive gradients, all finite, and
+    the two agree to the level at which two identical runs of the library convolutions agree with each other."""
+    from gloria.models import cnn_backbones as CB
+    torch.manual_seed(0)
+    model, _, _ = CB.resnet_50(pretrained=False)
+    model = model.to(DEV).to(memory_format=torch.channels_last).train()
+    x = torch.randn(16, 3, 128, 128, device=DEV).contiguous(memory_format=torch.channels_last)
+    proj = torch.randn(16, 2048, device=DEV)
+
+    def run():
+        model.zero_grad()
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = model(x)
+        (y.float() * proj).sum().backward()
+        return y.float().detach(), {n: p.grad.float().clone() for n, p in model.named_parameters() if p.grad is not None}
+    run()                                   # settles MIOpen's algorithm choice (the first call searches)
+    ya, ga = run()
+    y2, g2 = run()
+    noise = max(float((ga[n] - g2[n]).norm() / g2[n].norm()) for n in g2 if float(g2[n].norm()) > 1e-4)
+
+    def plain(self, t):
+        for blk in self:
+            t = blk(t, fork=False)
+        return t
+    monkeypatch.setattr(CB._Stage, "forward", plain)
+    yb, gb = run()
+    assert set(ga) == set(gb) and all(torch.isfinite(v).all() for v in ga.values())
+    worst = max(float((ga[n] - gb[n]).norm() / gb[n].norm()) for n in gb if float(gb[n].norm()) > 1e-4)
+    print(f"[resnet forked vs plain] worst parameter-gradient relative difference {worst:.4f}; run-to-run {noise:.4f}")
+    assert worst < max(3 * noise, 5e-2), (worst, noise)
