@@ -138,8 +138,15 @@ def ptr(t):
     return None if t is None else t.data_ptr()
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream():
-    return c_void_p(torch.cuda.current_stream().cuda_stream)
+    """the current HIP stream of the current device as a plain int (ctypes converts it for a void* parameter); the raw
+    accessor avoids building a torch.cuda.Stream object per launch (the 32-pair step is bound by host time)"""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
+    return torch.cuda.current_stream().cuda_stream
 
 
 def require_cuda(*tensors):
