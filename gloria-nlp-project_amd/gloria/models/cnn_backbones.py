@@ -52,10 +52,12 @@ class _Stage(nn.Sequential):
     """nn.Sequential of bottlenecks (same child names); inside the stage a block hands its output to the next as a
     SkipPair, the stage itself returns a tensor."""
 
-    def forward(self, x):
+    def forward(self, x, fork_out=False):
+        """fork_out: also the LAST block returns a SkipPair (the caller feeds it to the next stage, whose first block
+        reads `main` with its convolution and `skip` with its downsample branch)."""
         blocks = list(self)
         for i, blk in enumerate(blocks):
-            x = blk(x, fork=i + 1 < len(blocks))
+            x = blk(x, fork=fork_out or i + 1 < len(blocks))
         return x
 
 
@@ -92,7 +94,7 @@ class ResNet50(nn.Module):
 
     def forward(self, x):
         x = fused_maxpool(self.maxpool, fused_bn_act(self.bn1, self.conv1(x)))
-        x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
+        x = self.layer4(self.layer3(self.layer2(self.layer1(x, fork_out=True), fork_out=True)))
         return self.fc(torch.flatten(self.avgpool(x), 1))
 
 

@@ -68,8 +68,8 @@ class ImageEncoder(nn.Module):
         x = _resize_299(x)
         m = self.model
         x = fused_maxpool(m.maxpool, fused_bn_act(m.bn1, m.conv1(x)))         # (B, 64, 75, 75)
-        x = m.layer1(x)                                  # (B, 256, 75, 75)
-        x = m.layer2(x)                                  # (B, 512, 38, 38)
+        x = m.layer1(x, fork_out=True)                   # (B, 256, 75, 75); stage outputs travel as (main, skip) pairs
+        x = m.layer2(x, fork_out=True)                   # (B, 512, 38, 38)
         x = m.layer3(x)                                  # (B, 1024, 19, 19)
         local_features = x
         x = m.layer4(x)                                  # (B, 2048, 10, 10)

@@ -167,7 +167,7 @@ def test_resnet_with_forked_block_outputs_trains(monkeypatch):
     y2, g2 = run()
     noise = max(float((ga[n] - g2[n]).norm() / g2[n].norm()) for n in g2 if float(g2[n].norm()) > 1e-4)
 
-    def plain(self, t):
+    def plain(self, t, fork_out=False):
         for blk in self:
             t = blk(t, fork=False)
         return t
