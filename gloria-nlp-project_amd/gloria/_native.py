@@ -213,8 +213,10 @@ class TilePlan:
         self.n_sent, self.n_tiles, self.n_slots = n, nt, nt * TILE_WORDS
         self.sent_slot0_host = slot0
         self.n_words = int(cl.sum())
+        head = n + n + (nt + 1) + bound + nt + self.n_single + self.n_pair + self.n_all
+        pad = np.zeros((-head) % 64, dtype=np.int32)     # the descriptors start on a 256-byte boundary (16-byte LDS-DMA pieces)
         pack = np.concatenate([cl, slot0, tile_first[: nt + 1], order, nsub[:nt], singles[:self.n_single],
-                               pairs[:self.n_pair], alls[:self.n_all], desc[:self.n_pair * 64]]).astype(np.int32)
+                               pairs[:self.n_pair], alls[:self.n_all], pad, desc[:self.n_pair * 64]]).astype(np.int32)
         dev = torch.from_numpy(pack).to(device, non_blocking=True)
         o = 0
         self.cap_lens = dev[o:o + n]; o += n
@@ -224,7 +226,7 @@ class TilePlan:
         self.tile_nsub = dev[o:o + nt]; o += nt
         self.single_tile = dev[o:o + self.n_single]; o += self.n_single
         self.pair_tile = dev[o:o + self.n_pair]; o += self.n_pair
-        self.all_tile = dev[o:o + self.n_all]; o += self.n_all
+        self.all_tile = dev[o:o + self.n_all]; o += self.n_all + len(pad)
         self.pair_desc = dev[o:o + self.n_pair * 64] if self.n_pair else None
         self._dev = dev
         self._word_index = None
