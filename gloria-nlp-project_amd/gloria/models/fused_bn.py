@@ -20,7 +20,13 @@ ENABLED = os.environ.get("GLR_FUSED_BN", "1") != "0"
 _WS = {}            # device index -> fp32 workspace for the partial sums (all launches of a device share one stream order)
 
 
-def _workspace(dev, n):
+_WS_FLOATS = {}     # (rows, channels) -> glr_bn_workspace_floats: one ctypes call per shape, not per launch (host time)
+
+
+def _workspace(dev, R, c):
+    n = _WS_FLOATS.get((R, c))
+    if n is None:
+        n = _WS_FLOATS[(R, c)] = int(N.lib().glr_bn_workspace_floats(R, c))
     ws = _WS.get(dev.index)
     if ws is None or ws.numel() < n:
         ws = torch.empty(max(n, 1 << 20), dtype=torch.float32, device=dev)
@@ -37,7 +43,7 @@ class _BNAct(torch.autograd.Function):
         dev = x.device
         y = torch.empty_like(x)                              # channels_last like x
         stats = torch.empty(2, c, dtype=torch.float32, device=dev)
-        ws = _workspace(dev, L.glr_bn_workspace_floats(R, c))
+        ws = _workspace(dev, R, c)
         N.check(L.glr_bn_act_fwd(N.ptr(x), N.ptr(residual), N.ptr(weight), N.ptr(bias), R, c, float(eps), float(momentum),
                                  1 if relu else 0, N.ptr(run_mean), N.ptr(run_var), N.ptr(nbt), stats.data_ptr(), stats.data_ptr() + 4 * c,
                                  N.ptr(ws), N.ptr(y), N.stream()), "glr_bn_act_fwd")
@@ -70,7 +76,7 @@ class _BNAct(torch.autograd.Function):
         dx = torch.empty_like(x)
         dres = torch.empty_like(x) if ctx.has_res else None
         out = torch.empty(4, c, dtype=torch.float32, device=dev)
-        ws = _workspace(dev, L.glr_bn_workspace_floats(R, c))
+        ws = _workspace(dev, R, c)
         N.check(L.glr_bn_act_bwd(N.ptr(x), N.ptr(dy), N.ptr(dy2), N.ptr(y), N.ptr(weight), N.ptr(bias), stats.data_ptr(), stats.data_ptr() + 4 * c,
                                  R, c, 1 if ctx.relu else 0, 1 if ctx.has_res else 0, N.ptr(ws), N.ptr(out), N.ptr(dx),
                                  N.ptr(dres), N.stream()), "glr_bn_act_bwd")

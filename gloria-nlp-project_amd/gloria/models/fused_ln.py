@@ -22,7 +22,13 @@ ENABLED = os.environ.get("GLR_FUSED_LN", "1") != "0"
 _WS = {}
 
 
-def _workspace(dev, n):
+_WS_FLOATS = {}
+
+
+def _workspace(dev, R, H):
+    n = _WS_FLOATS.get((R, H))
+    if n is None:
+        n = _WS_FLOATS[(R, H)] = int(N.lib().glr_ln_workspace_floats(R, H))
     ws = _WS.get(dev.index)
     if ws is None or ws.numel() < n:
         ws = torch.empty(max(n, 1 << 21), dtype=torch.float32, device=dev)
@@ -72,7 +78,7 @@ class _DropAddLN(torch.autograd.Function):
         d_inp = torch.empty(h.shape, dtype=torch.float32, device=dev)
         d_h = torch.empty(h.shape, dtype=torch.bfloat16, device=dev)
         dgb = torch.empty(2, H, dtype=torch.float32, device=dev)
-        ws = _workspace(dev, L.glr_ln_workspace_floats(R, H))
+        ws = _workspace(dev, R, H)
         N.check(L.glr_drop_add_ln_bwd(N.ptr(d32), N.ptr(d16), N.ptr(h), N.ptr(inp), N.ptr(weight), N.ptr(stats), N.ptr(mask), R, H,
                                       ctx.p, N.ptr(d_inp), N.ptr(d_h), N.ptr(ws), N.ptr(dgb), c_off(dgb, H), N.stream()),
                 "glr_drop_add_ln_bwd")
