@@ -14,6 +14,8 @@ not reproduced.
 """
 
 import numpy as np
+import os
+
 import torch
 import torch.nn as nn
 
@@ -42,6 +44,17 @@ class PositionEmbeddings(nn.Module):
                  .expand(*spatial_shape, pos_dim) for i, e in enumerate(embs)]
         pad = torch.zeros(*spatial_shape, self.hidden_size - len(spatial_shape) * pos_dim, device=device)
         return torch.cat(embs + [pad], -1)
+
+
+_ENCODER_STREAMS = os.environ.get("GLR_ENCODER_STREAMS", "1") != "0"     # two-stream encoders (A/B switch)
+_SIDE = {}
+
+
+def _side_stream(dev):
+    s = _SIDE.get(dev.index)
+    if s is None:
+        s = _SIDE[dev.index] = torch.cuda.Stream(device=dev)
+    return s
 
 
 class GLoRIA(nn.Module):
@@ -178,6 +191,23 @@ class GLoRIA(nn.Module):
         return shared + share
 
     def forward(self, x):
+        if _ENCODER_STREAMS and x["imgs"].is_cuda and torch.is_grad_enabled() and not (self.dist is not None and self.dist.active):
+            # The two encoders are independent: the text encoder runs on a side HIP stream (autograd runs its backward
+            # there too), so its many short kernels fill the gaps between the image encoder's (88.6 -> 81 ms per step).
+            # Single-process training only: the data-parallel reducer gathers gradient buckets from its hooks on one
+            # stream and would need cross-stream events first.
+            cur = torch.cuda.current_stream()
+            side = _side_stream(x["imgs"].device)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                text_emb_l, text_emb_g, sents = self.text_encoder_forward(
+                    x["caption_ids"], x["attention_mask"], x["token_type_ids"])
+            img_emb_l, img_emb_g = self.image_encoder_forward(x["imgs"])
+            cur.wait_stream(side)
+            for t in (text_emb_l, text_emb_g):
+                if torch.is_tensor(t):
+                    t.record_stream(cur)
+            return img_emb_l, img_emb_g, text_emb_l, text_emb_g, sents
         img_emb_l, img_emb_g = self.image_encoder_forward(x["imgs"])
         text_emb_l, text_emb_g, sents = self.text_encoder_forward(
             x["caption_ids"], x["attention_mask"], x["token_type_ids"])
