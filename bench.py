@@ -2,7 +2,9 @@
 """bench.py - GLoRIA pretraining throughput on MI355X (image-text pairs / sec, whole job).
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
+    N > 1 from a bare shell: bench.py starts its own N rank processes (one per GPU, RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_* set, rank 0's JSON line relayed, non-zero exit if any rank fails) BEFORE anything touches the GPU;
+    under `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` it runs as the rank it is given.
 
 A "step" is one full optimisation step of imagenome_pretrain (BASELINE.json configs: ResNet-50 +
 BERT-base encoders, local + global contrastive loss through the HIP kernels, backward, gradient
@@ -33,18 +35,23 @@ for p in (ROOT, os.path.join(ROOT, "gloria-nlp-project_amd")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-import torch  # noqa: E402
+torch = None                    # imported by main() AFTER the launcher decision: the parent of a multi-rank run stays off the GPU
 
 GLOBAL_BATCH = 256
 PEAK_BF16_MFMA = 2.5e15        # dense, FLOP/s (MI355X_MICROARCH.md: ~2.5 PF dense bf16)
 PEAK_F32_MFMA = 157.3e12
 
 
-def build(cfg_batch, precision, device, dist_ctx, bert_layers=12, miopen_benchmark=False):
+def build(cfg_batch, precision, device, dist_ctx, bert_layers=12, miopen_benchmark=False, train_flags=False):
     from gloria import builder
     from gloria.config import pretrain_config
     from gloria.trainer import Trainer
     cfg = pretrain_config("imagenome", batch_size=cfg_batch)
+    if train_flags:
+        # the flags the reference's training job actually passes (/root/reference/submit_job.sh:15):
+        # --no_attn_vec --attention_entropy_loss_weight 1.0 --attention_divergence_loss_weight .1
+        cfg.model.gloria.merge({"no_attn_vec": True, "attention_entropy_loss_weight": 1.0,
+                                "attention_divergence_loss_weight": 0.1})
     if bert_layers != 12:
         cfg.set_path("model.text.bert_config", dict(num_hidden_layers=bert_layers))
     import warnings
@@ -147,6 +154,121 @@ def cpu_baseline(sample_batch=16, full=False):
             "step_s": step_s, "loss_only": loss}
 
 
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(n, argv, out_fd):
+    """`bench.py --gpus N` from a bare shell: start N rank processes of this script (one per GPU), relay rank 0's
+    JSON line, fail if any rank fails.  The parent imports neither torch nor anything that touches the GPU, and never
+    replaces itself: the ranks are plain child processes."""
+    import subprocess
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr.fileno(), stderr=None))
+    line, rc = b"", 0
+    try:
+        pending = set(range(n))
+        while pending:
+            for r in sorted(pending):
+                code = procs[r].poll()
+                if code is None:
+                    continue
+                pending.discard(r)
+                if r == 0:
+                    line = procs[0].stdout.read()
+                if code != 0:
+                    _say(f"rank {r} exited with code {code}: stopping the other ranks")
+                    rc = code if code > 0 else 1
+                    pending.clear()
+                    break
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=20)
+            except Exception:      # noqa: BLE001
+                p.kill()
+    if rc == 0:
+        out = [ln for ln in line.decode().splitlines() if ln.startswith("{")]
+        if len(out) != 1:
+            _say(f"rank 0 printed {len(out)} JSON lines (expected 1)")
+            rc = 1
+        else:
+            os.write(out_fd, (out[0] + "\n").encode())
+    return rc
+
+
+def selftest_step_loop(args, out_fd):
+    """CPU rehearsal of the launcher + rank plumbing (tests/test_bench_launcher.py): gloo, a tiny model, the bench's own
+    barrier / max-over-ranks timing and JSON line.  Not a measurement."""
+    import torch.distributed as dist
+    from gloria import dist as gdist
+    dctx = gdist.init_from_env("gloo")
+    world = dctx.world_size if dctx else 1
+    rank = dctx.rank if dctx else 0
+    if args.selftest_fail_rank is not None and rank == args.selftest_fail_rank:
+        raise SystemExit(3)
+    torch.manual_seed(7)
+    model = torch.nn.Sequential(torch.nn.Linear(16, 32), torch.nn.Tanh(), torch.nn.Linear(32, 4))
+    params = list(model.parameters())
+    opt = torch.optim.Adam(params, lr=1e-2)
+    GB = args.global_batch if args.global_batch % world == 0 else 8 * world
+    x = torch.randn(GB, 16, generator=torch.Generator().manual_seed(1))[rank::world]
+    y = torch.randn(GB, 4, generator=torch.Generator().manual_seed(2))[rank::world]
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        loss = ((model(x) - y) ** 2).sum() / GB
+        loss.backward()
+        if dctx:
+            dctx.allreduce_grads(params)
+        opt.step()
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+    if dctx:
+        dctx.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    if dctx:
+        dctx.barrier()
+    elapsed = time.perf_counter() - t0
+    if dctx:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        tot = dctx.all_reduce_scalar(loss)
+    else:
+        tot = loss.detach()
+    if rank == 0:
+        rec = {"metric": "selftest (launcher rehearsal, not a measurement)", "value": GB * args.steps / elapsed,
+               "unit": "rows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+               "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": "selftest", "global_batch": GB, "per_gpu_batch": GB // world,
+                          "world_size_seen": dist.get_world_size() if dctx else 1, "backend": "gloo",
+                          "final_loss": float(tot)}}
+        os.write(out_fd, (json.dumps(rec) + "\n").encode())
+    if dctx:
+        dctx.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     # the contract is ONE JSON line on stdout: libraries that print to fd 1 (RCCL's version banner at communicator
     # creation) are sent to stderr, the line itself goes to the saved descriptor
@@ -165,7 +287,21 @@ def main():
     ap.add_argument("--bert-layers", type=int, default=12)
     ap.add_argument("--global-batch", type=int, default=GLOBAL_BATCH,
                     help="experiments only: the metric is defined at the default 256")
+    ap.add_argument("--train-flags", action="store_true",
+                    help="the reference's real training flags (submit_job.sh:15): no_attn_vec + attention entropy 1.0 + "
+                         "divergence 0.1 regularisers (experiments: the metric is defined without them)")
+    ap.add_argument("--selftest", action="store_true", help="CPU / gloo rehearsal of the launcher (tests only)")
+    ap.add_argument("--selftest-fail-rank", type=int, default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # bare `bench.py --gpus N`: become the launcher (nothing below this line runs in the parent)
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:], out_fd))
+    global torch
+    import torch as _torch
+    torch = _torch
+    if args.selftest:
+        return selftest_step_loop(args, out_fd)
 
     from gloria import dist as gdist
     from gloria import miopen_db
@@ -174,8 +310,8 @@ def main():
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: start bench.py bare (it launches its own ranks) or "
+                         f"under torch.distributed.run with --nproc-per-node {args.gpus}")
     dctx = gdist.init_from_env("nccl") if (world > 1 or os.environ.get("GLR_FORCE_DIST") == "1") else None
     rank = dctx.rank if dctx else 0
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -186,7 +322,7 @@ def main():
     per_rank = GB // world
 
     use_find = miopen_db.activate(per_rank)   # before the first convolution
-    cfg, model, trainer = build(per_rank, args.precision, device, dctx, args.bert_layers, use_find)
+    cfg, model, trainer = build(per_rank, args.precision, device, dctx, args.bert_layers, use_find, args.train_flags)
 
     # synthetic global batch, identical on every rank; rank r takes rows r::world (length-balanced)
     full = make_batch(GB, seed=1234, lengths=args.lengths)
@@ -200,8 +336,16 @@ def main():
         torch.cuda.synchronize()
 
     _say(f"model built; {args.warmup} warm-up + {args.steps} timed steps at per-GPU batch {per_rank} ...")
-    for _ in range(args.warmup):
+    first_step_s = None
+    for i in range(args.warmup):
+        t_w = time.perf_counter()
         trainer.training_step(model, batch)
+        if i == 0:
+            # warm-up step 1 holds every first-use cost (MIOpen solver lookup / search, kernel loads, allocator growth):
+            # with the find-db resolving every convolution it takes seconds; tens of seconds mean MIOpen searched
+            torch.cuda.synchronize()
+            first_step_s = time.perf_counter() - t_w
+            _say(f"warm-up step 1 took {first_step_s:.1f} s")
     sync()
     GL.PROFILE = {}
     t0 = time.perf_counter()
@@ -260,6 +404,9 @@ def main():
                                    "contrastive loss, full training step (fwd+bwd+clip+Adam)",
                        "global_batch": GB, "per_gpu_batch": per_rank, "image": "224x224 -> 299x299",
                        "tokens": 97, "caption_lengths": args.lengths, "miopen_find_db": bool(use_find),
+                       "first_step_s": first_step_s, "train_flags": bool(args.train_flags),
+                       "world_size_seen": torch.distributed.get_world_size() if dctx else 1,
+                       "encoder_streams": int(getattr(trainer, "encoder_streams", -1)),
                        "kernel_launches_per_step": launches, "sum_cap_lens": cap_lens_sum,
                        "parallelism": f"dp{world}" + (" (text-embedding all-gather + grad all-reduce, RCCL)" if world > 1 else ""),
                        "final_loss": float(loss)},

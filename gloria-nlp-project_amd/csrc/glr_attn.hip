@@ -471,7 +471,8 @@ extern "C" int glr_attn_fwd(const void* q, const void* k, const void* v, const u
   if (!o || !lse || (p_drop > 0.f && !keep) || L > glr_attn_max_tokens(0)) return GLR_EINVAL;
   p.o = (unsigned short*)o; p.lse = lse; p.keep = keep;
   const int lds = (int)attn_lds_fwd(L);
-  if (hipFuncSetAttribute((const void*)k_attn_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return GLR_ELAUNCH;
+  static GlrLdsAttr lds_fwd;
+  if (glr_ensure_lds(lds_fwd, (const void*)k_attn_fwd, lds) != GLR_OK) return GLR_ELAUNCH;
   hipLaunchKernelGGL(k_attn_fwd, dim3(B * n_heads), dim3(AT_NT), lds, (hipStream_t)stream, p);
   GLR_CHECK_LAUNCH();
   return GLR_OK;
@@ -487,8 +488,9 @@ extern "C" int glr_attn_bwd(const void* q, const void* k, const void* v, const v
   p.o = (unsigned short*)const_cast<void*>(o); p.d_o = (const unsigned short*)d_o; p.lse = const_cast<float*>(lse);
   p.keep = const_cast<unsigned*>(keep); p.dq = (unsigned short*)dq; p.dk = (unsigned short*)dk; p.dv = (unsigned short*)dv;
   const int lds_q = (int)attn_lds_bwd_q(L), lds_kv = (int)attn_lds_bwd_kv(L);
-  if (hipFuncSetAttribute((const void*)k_attn_bwd_q, hipFuncAttributeMaxDynamicSharedMemorySize, lds_q) != hipSuccess) return GLR_ELAUNCH;
-  if (hipFuncSetAttribute((const void*)k_attn_bwd_kv, hipFuncAttributeMaxDynamicSharedMemorySize, lds_kv) != hipSuccess) return GLR_ELAUNCH;
+  static GlrLdsAttr lds_bq, lds_bkv;
+  if (glr_ensure_lds(lds_bq, (const void*)k_attn_bwd_q, lds_q) != GLR_OK) return GLR_ELAUNCH;
+  if (glr_ensure_lds(lds_bkv, (const void*)k_attn_bwd_kv, lds_kv) != GLR_OK) return GLR_ELAUNCH;
   hipLaunchKernelGGL(k_attn_bwd_q, dim3(B * n_heads), dim3(AT_NT), lds_q, (hipStream_t)stream, p);
   GLR_CHECK_LAUNCH();
   hipLaunchKernelGGL(k_attn_bwd_kv, dim3(B * n_heads), dim3(AT_NT), lds_kv, (hipStream_t)stream, p);

@@ -271,16 +271,8 @@ struct BnPlan { int cg_per_blk, col_blocks, n_part; };
 // pass with one and a bit rounds of workgroups ends with most of the chip idle), split over the channel blocks;
 // never more parts than slabs
 constexpr int BN_MAX_WG = 2048;
-int bn_resident(const void* fn) {
-  static int n_cu = 0;
-  if (n_cu == 0) {
-    int dev = 0;
-    hipDeviceProp_t pr;
-    n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ? pr.multiProcessorCount : 256;
-  }
-  int occ = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, BN_NT, 0) != hipSuccess || occ < 1) occ = 2;
-  const int n = n_cu * occ;
+int bn_resident(GlrOccupancy& occ, const void* fn) {
+  const int n = glr_dev_cus() * occ.get(fn, BN_NT);     // per-device tables (glr_common.h): no library-global state
   return n > BN_MAX_WG ? BN_MAX_WG : n;
 }
 BnPlan bn_plan(long long R, int C, int resident, int un) {
@@ -311,7 +303,8 @@ extern "C" int glr_bn_act_fwd(const void* x, const void* residual, const float* 
                               void* stream) {
   if (!x || !gamma || !beta || !mean || !invstd || !workspace || !y || !bn_shape_ok(R, C)) return GLR_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-  static const int res0 = bn_resident((const void*)k_bn_reduce<0, false>);
+  static GlrOccupancy occ0;
+  const int res0 = bn_resident(occ0, (const void*)k_bn_reduce<0, false>);
   const BnPlan pl = bn_plan(R, C, res0, 8);
   hipLaunchKernelGGL((k_bn_reduce<0, false>), dim3(pl.col_blocks, pl.n_part), dim3(BN_NT), 0, st, (const unsigned short*)x,
                      nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, R, C, 0, pl.n_part, workspace, nullptr, nullptr);
@@ -340,8 +333,9 @@ extern "C" int glr_bn_act_bwd(const void* x, const void* dy, const void* dy2, co
       (has_residual && (!y || !dres)) || (dy2 && !has_residual))
     return GLR_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-  static const int res1 = bn_resident((const void*)k_bn_reduce<1, false>);
-  static const int res2 = bn_resident((const void*)k_bn_reduce<1, true>);
+  static GlrOccupancy occ1, occ2;
+  const int res1 = bn_resident(occ1, (const void*)k_bn_reduce<1, false>);
+  const int res2 = bn_resident(occ2, (const void*)k_bn_reduce<1, true>);
   const BnPlan pl = bn_plan(R, C, has_residual ? res2 : res1, 4);
   const dim3 rgrid(pl.col_blocks, pl.n_part);
   if (has_residual)

@@ -17,6 +17,51 @@ typedef __attribute__((ext_vector_type(2))) _Float16 h2;
     if (hipGetLastError() != hipSuccess) return GLR_ELAUNCH; \
   } while (0)
 
+// Per-device launch facts, looked up once per (kernel, device) instead of once per launch: hipFuncSetAttribute and the
+// occupancy query cost microseconds of host time each, which a 32-pair training step pays ~250 times.  The tables are
+// immutable after their first fill (benign race: two threads may both fill an entry with the same value).
+#include <atomic>
+constexpr int GLR_MAX_DEV = 16;
+inline int glr_cur_dev() {
+  int dev = 0;
+  return (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < GLR_MAX_DEV) ? dev : -1;
+}
+struct GlrLdsAttr {                 // one object per kernel: largest dynamic-LDS size already granted on each device
+  std::atomic<int> have[GLR_MAX_DEV];
+  GlrLdsAttr() { for (auto& h : have) h.store(0, std::memory_order_relaxed); }
+};
+inline int glr_ensure_lds(GlrLdsAttr& a, const void* fn, int lds) {
+  const int dev = glr_cur_dev();
+  if (dev >= 0 && a.have[dev].load(std::memory_order_relaxed) >= lds) return GLR_OK;
+  if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return GLR_ELAUNCH;
+  if (dev >= 0) a.have[dev].store(lds, std::memory_order_relaxed);
+  return GLR_OK;
+}
+inline int glr_dev_cus() {          // compute units of the current device
+  static std::atomic<int> n_cu[GLR_MAX_DEV];
+  const int dev = glr_cur_dev();
+  int n = dev >= 0 ? n_cu[dev].load(std::memory_order_relaxed) : 0;
+  if (n == 0) {
+    int v = 0;
+    n = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev >= 0 ? dev : 0) == hipSuccess && v > 0) ? v : 256;
+    if (dev >= 0) n_cu[dev].store(n, std::memory_order_relaxed);
+  }
+  return n;
+}
+struct GlrOccupancy {               // one object per kernel: resident workgroups per CU at `threads` threads, no dynamic LDS
+  std::atomic<int> occ[GLR_MAX_DEV];
+  GlrOccupancy() { for (auto& o : occ) o.store(0, std::memory_order_relaxed); }
+  int get(const void* fn, int threads) {
+    const int dev = glr_cur_dev();
+    int v = dev >= 0 ? occ[dev].load(std::memory_order_relaxed) : 0;
+    if (v == 0) {
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, fn, threads, 0) != hipSuccess || v < 1) v = 2;
+      if (dev >= 0) occ[dev].store(v, std::memory_order_relaxed);
+    }
+    return v;
+  }
+};
+
 __device__ __forceinline__ unsigned short f2bf(float x) {
   // plain cast: hipcc emits v_cvt_pk_bf16_f32 (round to nearest even, NaN preserved)
   return __builtin_bit_cast(unsigned short, static_cast<__bf16>(x));

@@ -1697,14 +1697,12 @@ int launch(LaParams& p, int op_dtype, void* stream) {
 #define GLR_LAUNCH_K1(OP, FULL)                                                                                      \
   do {                                                                                                               \
     if (BWD && (p.damean != nullptr || p.dattn != nullptr)) {                                                        \
-      if (hipFuncSetAttribute((const void*)k_local_attn<OP, BWD, FULL, BWD>,                                         \
-                              hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)                        \
-        return GLR_ELAUNCH;                                                                                          \
+      static GlrLdsAttr la_;                                                                                         \
+      if (glr_ensure_lds(la_, (const void*)k_local_attn<OP, BWD, FULL, BWD>, lds) != GLR_OK) return GLR_ELAUNCH;     \
       hipLaunchKernelGGL((k_local_attn<OP, BWD, FULL, BWD>), dim3(grid), dim3(NTHR), lds, st, p);                     \
     } else {                                                                                                         \
-      if (hipFuncSetAttribute((const void*)k_local_attn<OP, BWD, FULL, false>,                                       \
-                              hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)                        \
-        return GLR_ELAUNCH;                                                                                          \
+      static GlrLdsAttr la_;                                                                                         \
+      if (glr_ensure_lds(la_, (const void*)k_local_attn<OP, BWD, FULL, false>, lds) != GLR_OK) return GLR_ELAUNCH;   \
       hipLaunchKernelGGL((k_local_attn<OP, BWD, FULL, false>), dim3(grid), dim3(NTHR), lds, st, p);                   \
     }                                                                                                                \
   } while (0)
@@ -1734,7 +1732,8 @@ int launch_pair(LaParams& p, int op_dtype, void* stream) {
 #ifdef GLR_ABLATE
   { const char* e = getenv("GLR_K1_DBG"); p.dbg = e ? atoi(e) : 0; }
 #endif
-  if (hipFuncSetAttribute((const void*)k_local_attn_pw<OpBF16>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return GLR_ELAUNCH;
+  static GlrLdsAttr la_pw;
+  if (glr_ensure_lds(la_pw, (const void*)k_local_attn_pw<OpBF16>, lds) != GLR_OK) return GLR_ELAUNCH;
   hipLaunchKernelGGL((k_local_attn_pw<OpBF16>), dim3(grid), dim3(NTHR), lds, (hipStream_t)stream, p);
   GLR_CHECK_LAUNCH();
   return GLR_OK;
@@ -1755,10 +1754,12 @@ int launch_pair_bwd(LaParams& p, int op_dtype, void* stream) {
   { const char* e = getenv("GLR_K1_DBG"); p.dbg = e ? atoi(e) : 0; }
 #endif
   if (p.a1buf != nullptr) {
-    if (hipFuncSetAttribute((const void*)k_local_attn_pw_bwd<OpBF16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return GLR_ELAUNCH;
+    static GlrLdsAttr la_b1;
+    if (glr_ensure_lds(la_b1, (const void*)k_local_attn_pw_bwd<OpBF16, true>, lds) != GLR_OK) return GLR_ELAUNCH;
     hipLaunchKernelGGL((k_local_attn_pw_bwd<OpBF16, true>), dim3(grid), dim3(NTHR), lds, (hipStream_t)stream, p);
   } else {
-    if (hipFuncSetAttribute((const void*)k_local_attn_pw_bwd<OpBF16, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return GLR_ELAUNCH;
+    static GlrLdsAttr la_b0;
+    if (glr_ensure_lds(la_b0, (const void*)k_local_attn_pw_bwd<OpBF16, false>, lds) != GLR_OK) return GLR_ELAUNCH;
     hipLaunchKernelGGL((k_local_attn_pw_bwd<OpBF16, false>), dim3(grid), dim3(NTHR), lds, (hipStream_t)stream, p);
   }
   GLR_CHECK_LAUNCH();
