@@ -304,7 +304,7 @@ def main():
         return selftest_step_loop(args, out_fd)
 
     from gloria import dist as gdist
-    from gloria import miopen_db
+    from gloria import miopen_env
     from gloria.datasets.synthetic import make_batch
     from gloria.loss import gloria_loss as GL
 
@@ -321,7 +321,7 @@ def main():
     assert GB % world == 0
     per_rank = GB // world
 
-    use_find = miopen_db.activate(per_rank)   # before the first convolution
+    use_find = miopen_env.activate()   # before the first convolution: find mode without the naive reference solvers
     cfg, model, trainer = build(per_rank, args.precision, device, dctx, args.bert_layers, use_find, args.train_flags)
 
     # synthetic global batch, identical on every rank; rank r takes rows r::world (length-balanced)
@@ -403,7 +403,7 @@ def main():
             "config": {"workload": "imagenome_pretrain_config.yaml: ResNet-50 + BERT-base(12L) + local+global "
                                    "contrastive loss, full training step (fwd+bwd+clip+Adam)",
                        "global_batch": GB, "per_gpu_batch": per_rank, "image": "224x224 -> 299x299",
-                       "tokens": 97, "caption_lengths": args.lengths, "miopen_find_db": bool(use_find),
+                       "tokens": 97, "caption_lengths": args.lengths, "miopen_find_mode": bool(use_find),
                        "first_step_s": first_step_s, "train_flags": bool(args.train_flags),
                        "world_size_seen": torch.distributed.get_world_size() if dctx else 1,
                        "encoder_streams": int(getattr(trainer, "encoder_streams", -1)),

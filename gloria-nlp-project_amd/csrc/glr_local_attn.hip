@@ -41,7 +41,7 @@
 #include <cstdlib>
 #include <type_traits>
 
-#include "glr_common.h"
+#include "glr_k1.h"
 
 #ifndef GLR_STAGGER
 #define GLR_STAGGER 1
@@ -53,59 +53,7 @@ extern "C" int glr_tile_capacity(int op_dtype) { return op_dtype == GLR_F32 ? 32
 
 namespace {
 
-constexpr int TW = GLR_TILE_WORDS;  // 64 word slots per tile
 constexpr int NTHR = 512;
-constexpr int WSTAT = 4;            // floats per (image, slot) saved by forward: Z, cos, |c|^2, unused
-
-struct LaParams {
-  const unsigned char* vt;      // [B_img][S_pad][D]
-  const unsigned char* gram;    // [B_img][S_pad][S_pad]
-  const unsigned char* tp;      // [n_slots][D]
-  const float* tnorm;           // [n_slots]
-  const int* sent_slot0;
-  const int* cap_lens;
-  const int* tile_first;
-  const int* order;
-  const int* tile_nsub;
-  const int* item_tile;         // first tiles of the work items of this launch (single tiles or pairs)
-  int n_items;
-  int n_tiles, n_sent, n_slots, B_img, D, S_eff, S_pad;
-  int tw;                       // populated word slots per tile: 64 (bf16) or 32 (fp32, LDS budget)
-  float temp1, temp2, temp3;
-  int agg;
-  float eps;
-  float* sim;                   // [B_img][ld_sim]   (fwd: out, bwd: in)
-  int ld_sim;
-  float* lse;                   // [B_img][n_sent][S_pad]  (fwd: optional out, bwd: in)
-  float* wstat;                 // [B_img][n_slots][WSTAT] (fwd: optional out, bwd: in)
-  float* attn;                  // fwd optional out
-  float* amean;                 // fwd optional out: [B_img][n_sent][S_pad] word-mean attention row of every pair
-  const float* damean;          // bwd optional in:  gradient w.r.t. amean
-  const float* dattn;           // bwd optional in:  gradient w.r.t. the diagonal attention maps (layout of attn)
-  const long long* attn_off;
-  int strip;
-  int pair_only, img_offset;
-  int img_block;                // pair kernel: images per L2 group (block -> (image, item) mapping)
-  const int* pair_desc;         // [n_pair][64] sentences + row flags of every forward pair (glr_plan_pair_desc)
-  unsigned* a1buf;              // optional [B_img][n_pair][8 waves][2][3][8][64] fp16 pairs of a1 in the pair kernels' own
-                                // register order: written by the forward, read by the backward instead of its score stream
-#ifdef GLR_ABLATE
-  int dbg;                      // diagnostic build only (libglr_ablate.so): phases to SKIP, GLR_K1_DBG bit mask
-#endif
-  // backward only
-  const float* dsim;            // [B_img][ld_sim]
-  unsigned char* xout;          // [n_slots][B_img][S_pad] op dtype
-  unsigned char* aout;          // [B_img][n_slots][S_pad] a2
-  float* gamma;                 // [B_img][n_slots]
-  float* beta;                  // [B_img][n_slots]
-  unsigned char* baout;         // optional [B_img][n_slots][S_pad] beta * a2 (the P3 operand image)
-  // LDS carve (bytes)
-  int off_img, off_small;
-#ifdef GLR_STAMPS
-  unsigned long long* stamps;   // diagnostic build only: [grid][12] s_memtime at phase boundaries
-  unsigned long long* stamps2;  // same, for the pair kernel's grid
-#endif
-};
 
 #ifdef GLR_STAMPS
 // per-wave stamps inside the P1 stream of the pair kernel: [workgroup][wave][chunk][3] = after the barrier,
@@ -239,14 +187,15 @@ __device__ __forceinline__ void stream_gemm_n(f32x16 (&acc)[3], f32x16 (&acc2)[3
     const int k = min(wave + 8 * i, winstr - 1);
     const int row = k * RPI + prow;
     const int g = pslot ^ ((row / RPB) & (PPR - 1));
-    // Operands are K-TILED in HBM (glr_tile_k): a block of R rows is stored [K chunk][row][CHB bytes], so
-    // every DMA piece reads 1 KiB of CONTIGUOUS memory (row-major operands gave 64-byte fragments of 16
-    // different rows per piece: half of every 128-byte line fetched twice, 27 B/clk/CU instead of ~48).
+    // Operands are K-TILED in HBM (glr_k1.h, glr_ktile_off): a block of R rows is stored [K chunk][32-row block]
+    // [16-byte slot][row], so every DMA piece (16 rows x 4 slots) reads four 256-byte runs of whole lines (row-major
+    // operands gave 64-byte fragments of 16 different rows per piece: half of every 128-byte line fetched twice,
+    // 27 B/clk/CU instead of ~48).
     // A row r of the ring = populated row (r % tw) of tile (r / tw); a tile block holds TW rows per chunk.
     const bool is_a = row < arows;
     const int tl = row / tw, rr = row - tl * tw;
-    const size_t off = is_a ? (size_t)tl * TW * apitch + (size_t)rr * CHB : (size_t)(row - arows) * CHB;
-    psrc[i] = (is_a ? asrc : bsrc) + off + g * 16;
+    const size_t off = is_a ? (size_t)tl * TW * apitch + (size_t)glr_ktile_off(rr, g) : (size_t)glr_ktile_off(row - arows, g);
+    psrc[i] = (is_a ? asrc : bsrc) + off;
     pstep[i] = (is_a ? TW : brows) * CHB;                    // bytes from one K chunk to the next
     pdst[i] = ring_lds + k * 1024;
   }
@@ -890,7 +839,6 @@ __global__ void __launch_bounds__(NTHR) k_local_attn(LaParams p) {
 // A sentence of 65..128 words owns both tiles: its two tiles keep separate table rows (row = tile) that are
 // combined in a fixed order behind a workgroup barrier (the only case with barriers inside the statistics).
 // LDS: [0, 2*IMG) images (earlier: P1 ring) | [2*IMG, +48 KiB) mx / sm half tables, then the 2-deep P3 ring | small.
-constexpr int PW_MAXSEG = 8;    // sentences per pair (planner: max_pair_seg); the spanning sentence of a long pair uses rows 0 / 1
 
 template <typename O>
 __global__ void __launch_bounds__(NTHR) k_local_attn_pw(LaParams p) {
@@ -1127,7 +1075,7 @@ __global__ void __launch_bounds__(NTHR) k_local_attn_pw(LaParams p) {
     if (!GLR_SKIP(4)) {
       float lc[3] = {0.f, 0.f, 0.f};
       unsigned* a1out = p.a1buf == nullptr ? nullptr
-                        : p.a1buf + (((size_t)b * p.n_items + rem / ib) * 8 + wave) * (2 * 3 * 8 * 64) + lane;
+                        : p.a1buf + (((size_t)b * p.a1_items + p.a1_base + rem / ib) * 8 + wave) * (2 * 3 * 8 * 64) + lane;
       unsigned char* imgw = img0 + t * IMG + (4 * h) * IMP + rbase * ESZ;   // + (blk * 32 + row(q)) * IMP + 128 * j * ESZ
       float* redt = red + t * 16 * TW + rslot * TW + 4 * h;                // + blk * 32 + row(q)
 #pragma unroll
@@ -1354,7 +1302,7 @@ __global__ void __launch_bounds__(NTHR) k_local_attn_pw_bwd(LaParams p) {
   unsigned a1k0[3][8], a1k1[3][8];                                // a1 as fp16 pairs (rows q, q + 1)
   if constexpr (A1IN) {
     // 48 coalesced dword loads per lane, in flight behind the whole set-up
-    const unsigned* a1in = p.a1buf + (((size_t)b * p.n_items + rem / ib) * 8 + wave) * (2 * 3 * 8 * 64) + lane;
+    const unsigned* a1in = p.a1buf + (((size_t)b * p.a1_items + p.a1_base + rem / ib) * 8 + wave) * (2 * 3 * 8 * 64) + lane;
 #pragma unroll
     for (int j = 0; j < 3; ++j)
 #pragma unroll
@@ -1778,7 +1726,7 @@ int fill_common(LaParams& p, const void* vt, const void* gram, const void* tp, c
   if (agg < 0 || agg > 2) return GLR_EINVAL;
   p.vt = (const unsigned char*)vt; p.gram = (const unsigned char*)gram; p.tp = (const unsigned char*)tp;
   p.tnorm = tnorm; p.sent_slot0 = sent_slot0; p.cap_lens = cap_lens; p.tile_first = tile_first; p.order = order;
-  p.tile_nsub = tile_nsub; p.item_tile = nullptr; p.n_items = 0; p.amean = nullptr; p.damean = nullptr; p.dattn = nullptr; p.pair_desc = nullptr; p.a1buf = nullptr; p.n_tiles = n_tiles; p.n_sent = n_sent;
+  p.tile_nsub = tile_nsub; p.item_tile = nullptr; p.n_items = 0; p.amean = nullptr; p.damean = nullptr; p.dattn = nullptr; p.pair_desc = nullptr; p.a1buf = nullptr; p.a1_items = 0; p.a1_base = 0; p.n_tiles = n_tiles; p.n_sent = n_sent;
   p.n_slots = n_tiles * TW; p.B_img = B_img;
   p.D = D; p.S_eff = S_eff; p.S_pad = S_pad; p.temp1 = temp1; p.temp2 = temp2; p.temp3 = temp3; p.agg = agg;
   p.eps = eps;
@@ -1799,7 +1747,7 @@ extern "C" int glr_local_attn_fwd(const void* vt, const void* gram, const void* 
                                   const int32_t* sent_slot0, const int32_t* cap_lens,
                                   const int32_t* tile_first, const int32_t* order, const int32_t* tile_nsub,
                                   const int32_t* single_tile, int n_single, const int32_t* pair_tile, int n_pair,
-                                  const int32_t* pair_desc,
+                                  int n_long_pair, const int32_t* pair_desc,
                                   int n_tiles, int n_sent, int B_img, int D, int S_eff, float temp1, float temp2,
                                   float temp3, int agg, float eps, float* sim, int ld_sim, float* lse, float* wstat,
                                   float* attn, const int64_t* attn_off, int strip, int pair_only, int img_offset,
@@ -1821,8 +1769,22 @@ extern "C" int glr_local_attn_fwd(const void* vt, const void* gram, const void* 
     if (rc != GLR_OK) return rc;
   }
   if (!pair_only && n_pair > 0) {
-    p.item_tile = pair_tile; p.n_items = n_pair; p.pair_desc = pair_desc; p.a1buf = (unsigned*)a1buf;
-    rc = launch_pair(p, op_dtype, stream);
+    if (n_long_pair < 0 || n_long_pair > n_pair) return GLR_EINVAL;
+    // The pairs of one 65..128-word sentence (a prefix of the pair list: the planner puts multi-tile sentences first) run
+    // the 8-wave pair kernel; the ordinary pairs (two whole tiles) run one 4-wave workgroup per tile, two per CU
+    // (glr_local_attn_t1.hip).  GLR_K1_T1=0 sends every pair to the pair kernel (A/B switch of tools/ and tests).
+    static const bool use_t1 = [] { const char* e = getenv("GLR_K1_T1"); return !(e && e[0] == '0'); }();
+    const int n_pw = (use_t1 && D % 128 == 0 && D >= 256) ? n_long_pair : n_pair;
+    p.a1buf = (unsigned*)a1buf; p.a1_items = n_pair;
+    if (n_pw > 0) {
+      p.item_tile = pair_tile; p.n_items = n_pw; p.pair_desc = pair_desc; p.a1_base = 0;
+      rc = launch_pair(p, op_dtype, stream);
+      if (rc != GLR_OK) return rc;
+    }
+    if (n_pair > n_pw) {
+      p.item_tile = pair_tile + n_pw; p.n_items = n_pair - n_pw; p.pair_desc = pair_desc + (size_t)64 * n_pw; p.a1_base = n_pw;
+      rc = glr_k1_launch_tiles(p, op_dtype, stream);
+    }
   }
   return rc;
 }
@@ -1859,6 +1821,7 @@ extern "C" int glr_local_attn_bwd(const void* vt, const void* gram, const void* 
   }
   if (n_pair > 0) {
     p.item_tile = pair_tile; p.n_items = n_pair; p.pair_desc = pair_desc; p.a1buf = (unsigned*)const_cast<void*>(a1buf);
+    p.a1_items = n_pair; p.a1_base = 0;
     rc = launch_pair_bwd(p, op_dtype, stream);
   }
   return rc;

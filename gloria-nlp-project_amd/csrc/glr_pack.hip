@@ -10,7 +10,7 @@
 #include <algorithm>
 #include <vector>
 
-#include "glr_common.h"
+#include "glr_k1.h"
 
 extern "C" int glr_version(void) { return 2; }
 
@@ -279,25 +279,36 @@ __global__ void __launch_bounds__(256) k_pack_regions(const void* __restrict__ i
     st_any(vt, ((size_t)b * S_pad + r0 + rl) * D + d0 + tx, op_dtype, tile[tx][rl]);
 }
 
-// Fast path of the training step: channels-last bf16 features -> bf16 operands.  One thread moves 16 bytes
-// (8 features of one region) and writes them TWICE: row-major vt (the gradient GEMMs' operand) and the K-tiled
-// copy the K1 streams read ([D*2 / 64][S_pad][64 bytes] per image) - one read of the features instead of a pack
-// pass plus a tiling pass.  Rows [S_eff, S_pad) are zero, the optional no-attention vector is row 0.
+// Fast path of the training step: channels-last bf16 features -> bf16 operands.  One workgroup moves a block of 32
+// regions x 512 bytes (256 features) and writes it TWICE: row-major vt (the gradient GEMMs' operand) and the K-tiled,
+// fragment-major copy the K1 streams read (glr_k1.h: [D*2 / 64][S_pad / 32][4 slots][32 rows][16 bytes] per image) -
+// one read of the features instead of a pack pass plus a tiling pass.  Both writes are whole 512-byte runs: the
+// tiled order is a transposition of (row, piece) inside the block, done through 16.5 KB of LDS (33-piece pitch: the
+// transposed read is conflict-free).  Rows [S_eff, S_pad) are zero, the optional no-attention vector is row 0.
+// grid (D*2 / 512, S_pad / 32, B), 256 threads.
 __global__ void __launch_bounds__(256) k_pack_regions_cl16(const uint4* __restrict__ img, const uint4* __restrict__ no_attn,
                                                            uint4* __restrict__ vt, uint4* __restrict__ vt_t, int D16,
-                                                           int S, int S_pad, int shift, size_t total) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;       // index of a 16-byte piece of vt
-  if (i >= total) return;
-  const int c = (int)(i % D16);                   // 16-byte piece inside the row
-  const size_t row = i / D16;
-  const int rp = (int)(row % S_pad);
-  const size_t b = row / S_pad;
-  uint4 v = make_uint4(0u, 0u, 0u, 0u);
-  if (rp < S + shift) v = (shift && rp == 0) ? no_attn[c] : img[(b * S + (rp - shift)) * D16 + c];
-  vt[i] = v;
-  if (vt_t) {
-    const int nch = D16 / 4;                      // 64-byte chunks per row
-    vt_t[((b * nch + (c >> 2)) * S_pad + rp) * 4 + (c & 3)] = v;
+                                                           int S, int S_pad, int shift) {
+  __shared__ uint4 tile[32][33];
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  const size_t b = blockIdx.z;
+  const int t = threadIdx.x;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int q = t + 256 * k, rl = q >> 5, c = q & 31;      // 32 consecutive threads = 512 contiguous bytes of one row
+    const int rp = r0 + rl;
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (rp < S + shift) v = (shift && rp == 0) ? no_attn[c0 + c] : img[(b * S + (rp - shift)) * D16 + c0 + c];
+    vt[(b * S_pad + rp) * D16 + c0 + c] = v;
+    tile[rl][c] = v;
+  }
+  if (vt_t == nullptr) return;
+  __syncthreads();
+  const size_t nch = D16 / 4;                                // 64-byte chunks per row
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int q = t + 256 * k, ch = q >> 7, slot = (q >> 5) & 3, rl = q & 31;   // 128 consecutive threads = one 2-KiB block
+    vt_t[((b * nch + (c0 >> 2) + ch) * S_pad + r0) * 4 + slot * 32 + rl] = tile[rl][ch * 4 + slot];
   }
 }
 
@@ -343,18 +354,20 @@ __global__ void __launch_bounds__(256) k_word_norms(const void* __restrict__ tp,
   if (lane == 0) tnorm[slot] = sqrtf(s);
 }
 
-// K-tiling copy: every block of `rows` rows x `row_bytes` bytes is rewritten as [row_bytes / 64][rows][64 B],
-// so that the K1 streams read 1-KiB contiguous pieces.  One thread moves 16 bytes; writes are linear.
+// K-tiling copy: every block of `rows` rows x `row_bytes` bytes is rewritten as [row_bytes / 64] chunks of `rows` * 64
+// bytes, fragment-major inside a chunk (glr_k1.h, glr_ktile_off).  One thread moves 16 bytes; writes are linear.
 // ones_row >= 0: row `ones_row` of every block is written as ones_cols elements of 1.0 (element size esz) followed
 // by zeros instead of being copied - the Gram operand's ones row (glr_local_attn_fwd, tile_rowflags).
 __global__ void k_tile_k(const uint4* __restrict__ src, uint4* __restrict__ dst, int rows, int nch, size_t total,
                          int ones_row, int ones_cols, int esz) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
-  const int s16 = (int)(i & 3);
-  const size_t t = i >> 2;
-  const int r = (int)(t % rows);
-  const size_t u = t / rows;
+  const int rl = (int)(i & 31);
+  const int s16 = (int)((i >> 5) & 3);
+  const size_t t = i >> 7;                        // 32-row block index over (block, chunk, row block)
+  const int nrb = rows >> 5;
+  const int r = (int)(t % nrb) * 32 + rl;
+  const size_t u = t / nrb;
   const int c = (int)(u % nch);
   const size_t blk = u / nch;
   uint4 v = src[((blk * rows + r) * nch + c) * 4 + s16];
@@ -376,7 +389,7 @@ __global__ void k_tile_k(const uint4* __restrict__ src, uint4* __restrict__ dst,
 
 static int tile_k_impl(const void* src, void* dst, int rows, long long n_blocks, int row_bytes, int ones_row, int ones_cols,
                        int esz, void* stream) {
-  if (!src || !dst || rows <= 0 || n_blocks <= 0 || row_bytes <= 0 || row_bytes % 64 != 0) return GLR_EINVAL;
+  if (!src || !dst || rows <= 0 || rows % 32 != 0 || n_blocks <= 0 || row_bytes <= 0 || row_bytes % 64 != 0) return GLR_EINVAL;
   const size_t total = (size_t)n_blocks * rows * (row_bytes / 16);
   const int nch = row_bytes / 64;
   hipLaunchKernelGGL(k_tile_k, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
@@ -405,13 +418,11 @@ static int pack_regions_impl(const void* img_features, int in_dtype, int in_layo
   const int S_pad = glr_region_pad(S + shift);
   if (S_pad > GLR_MAX_SPAD) return GLR_EINVAL;
   const bool aligned = ((uintptr_t)img_features % 16 == 0) && (!no_attn_vec || (uintptr_t)no_attn_vec % 16 == 0);
-  if (in_layout == 1 && in_dtype == GLR_BF16 && op_dtype == GLR_BF16 && aligned) {
-    // the training step's case: one 16-byte-per-thread pass that also emits the K-tiled copy
+  if (in_layout == 1 && in_dtype == GLR_BF16 && op_dtype == GLR_BF16 && aligned && D % 256 == 0) {
+    // the training step's case: one pass that also emits the K-tiled copy
     const int D16 = D * 2 / 16;
-    const size_t total = (size_t)B * S_pad * D16;
-    hipLaunchKernelGGL(k_pack_regions_cl16, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       (const uint4*)img_features, (const uint4*)no_attn_vec, (uint4*)vt, (uint4*)vt_t, D16, S, S_pad, shift,
-                       total);
+    hipLaunchKernelGGL(k_pack_regions_cl16, dim3(D16 / 32, S_pad / 32, B), dim3(256), 0, (hipStream_t)stream,
+                       (const uint4*)img_features, (const uint4*)no_attn_vec, (uint4*)vt, (uint4*)vt_t, D16, S, S_pad, shift);
     GLR_CHECK_LAUNCH();
     return GLR_OK;
   }

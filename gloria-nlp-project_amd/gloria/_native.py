@@ -36,7 +36,7 @@ SYMBOLS = {
     "glr_tile_gram": (c_int, [c_void_p, c_void_p, c_int, ctypes.c_longlong, c_int, c_int, c_void_p]),
     "glr_pack_words": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                c_int, c_int, c_int, c_void_p]),
-    "glr_local_attn_fwd": (c_int, [c_void_p] * 10 + [c_int, c_void_p, c_int, c_void_p] + [c_int] * 5 + [c_float] * 3 + [c_int, c_float, c_void_p, c_int,
+    "glr_local_attn_fwd": (c_int, [c_void_p] * 10 + [c_int, c_void_p, c_int, c_int, c_void_p] + [c_int] * 5 + [c_float] * 3 + [c_int, c_float, c_void_p, c_int,
                                    c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]),
                                    # ..., sim, ld, lse, wstat, attn, attn_off, strip, pair_only, img_offset, amean, a1buf, dtype, stream
     "glr_local_attn_bwd": (c_int, [c_void_p] * 10 + [c_int, c_void_p, c_int, c_void_p] + [c_int] * 5 + [c_float] * 3
@@ -190,6 +190,12 @@ class TilePlan:
         if rc != 0:
             raise ValueError(f"glr_plan_items failed ({rc})")
         self.n_single, self.n_pair, self.n_all = (int(c) for c in counts)
+        # pairs that are the two tiles of ONE 65..128-word sentence: a prefix of the pair list (multi-tile sentences
+        # are planned first); they run the 8-wave pair kernel, the rest one workgroup per tile
+        is_long = nsub[pairs[:self.n_pair]] == 2
+        self.n_long_pair = int(is_long.sum())
+        if not bool(is_long[:self.n_long_pair].all()):
+            raise RuntimeError("tile plan: long pairs are expected to lead the pair list")
         # run boundaries per tile and lane half for the forward pair kernel (full-width tiles only)
         flags = np.zeros(nt * 8, dtype=np.uint32)
         if self.n_pair:

@@ -89,8 +89,9 @@ def build_optimizer(cfg, lr, model):
         skip = set()
         if (cfg.model.text.last_n_layers or 1) > 1 and hasattr(model, "text_encoder"):
             skip = {id(p) for p in model.text_encoder.model.pooler.parameters()}
+        all_params = params
         params = [p for p in params if id(p) not in skip]
-        return ShadowAdam(params, lr=lr, betas=(0.5, 0.999), weight_decay=float(cfg.train.optimizer.weight_decay),
+        return ShadowAdam(params, all_params=all_params, lr=lr, betas=(0.5, 0.999), weight_decay=float(cfg.train.optimizer.weight_decay),
                           max_grad_norm=cfg.train.optimizer.flat_clip, shadow_ids=shadow_parameter_ids(model),
                           flat_grads=bool(cfg.train.optimizer.flat_grads))
 

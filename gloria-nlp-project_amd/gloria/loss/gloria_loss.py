@@ -146,7 +146,8 @@ def _k1_args(plan, vt, gram, tp, tnorm, B, D, s_eff, o, backward=False):
         items = (N.ptr(plan.all_tile), plan.n_all, None, 0, None)
     else:
         items = (N.ptr(plan.single_tile) if plan.n_single else None, plan.n_single,
-                 N.ptr(plan.pair_tile) if plan.n_pair else None, plan.n_pair, N.ptr(plan.pair_desc))
+                 N.ptr(plan.pair_tile) if plan.n_pair else None, plan.n_pair) \
+            + (() if backward else (plan.n_long_pair,)) + (N.ptr(plan.pair_desc),)
     return head + items + (plan.n_tiles, plan.n_sent, B, D, s_eff, o.temp1, o.temp2, o.temp3, N.AGG[o.agg], o.eps)
 
 

@@ -85,7 +85,9 @@ class _BNAct(torch.autograd.Function):
 
 def _fusable(bn, x, residual):
     c = x.shape[1] if x.dim() == 4 else 0
-    return (ENABLED and x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4 and bn.training and bn.affine
+    # exactly nn.BatchNorm2d: SyncBatchNorm (Trainer(sync_bn=True)) has the same attributes but its statistics span the
+    # process group - the per-rank kernels would silently turn the global-batch parity mode into per-rank BN
+    return (type(bn) is torch.nn.BatchNorm2d and ENABLED and x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4 and bn.training and bn.affine
             and bn.track_running_stats and bn.momentum is not None and 8 <= c <= 2048 and (c & (c - 1)) == 0
             and bn.weight.dtype == torch.float32 and bn.bias.dtype == torch.float32
             and x.is_contiguous(memory_format=torch.channels_last)

@@ -127,7 +127,7 @@ class ShadowAdam(torch.optim.Optimizer):
     """Adam (torch semantics) over flat buffers.  `shadow_ids`: ids of the parameters that become bf16 shadows."""
 
     def __init__(self, params, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_grad_norm=None, shadow_ids=(),
-                 flat_grads=False):
+                 flat_grads=False, all_params=None):
         """Gradients always stay where autograd puts them (one tensor per parameter: making `.grad` a view of a flat
         buffer costs an accumulation launch per parameter).  flat_grads=False (single process): the norm / Adam kernels
         read them through a pointer table.  flat_grads=True (data parallel): the reducer gathers every bucket's
@@ -136,7 +136,19 @@ class ShadowAdam(torch.optim.Optimizer):
         params = [p for p in params if p.requires_grad]
         if not params or not all(p.is_cuda for p in params):
             raise RuntimeError("ShadowAdam runs on GPU parameters (the flat kernels are HIP)")
-        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        # the group carries torch.optim.Adam's own keys (at their defaults) so that its state_dict() loads into a stock
+        # Adam and back
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=False, maximize=False,
+                                      foreach=None, capturable=False, differentiable=False, fused=None,
+                                      decoupled_weight_decay=False))
+        # `all_params`: every trainable parameter of the model in registration order, INCLUDING the ones this optimizer
+        # leaves out (builder.build_optimizer drops parameters the graph never reaches).  Checkpoints are written and
+        # read in that order - the layout torch.optim.Adam(model.parameters()) and the reference's Lightning
+        # checkpoints use - so the optimizer state maps BY PARAMETER, never by position in this optimizer's own list.
+        self.all_params = [p for p in (all_params if all_params is not None else params) if p.requires_grad]
+        own = {id(p) for p in params}
+        if not own <= {id(p) for p in self.all_params}:
+            raise ValueError("ShadowAdam: all_params must contain every optimised parameter")
         dev = params[0].device
         shadow_ids = set(shadow_ids)
         # reverse registration order: backward produces gradients roughly back to front, so consecutive ranges of a
@@ -212,17 +224,45 @@ class ShadowAdam(torch.optim.Optimizer):
                     if p.dtype != torch.float32:
                         p.data.copy_(m)
 
+    def state_dict(self):
+        """stock layout over `all_params` (the reference optimizer's parameter list): index = position of the parameter
+        in the model's registration order; parameters this optimizer leaves out simply have no state entry"""
+        own = {id(p) for grp in self.param_groups for p in grp["params"]}
+        state = {i: {k: (v.clone() if torch.is_tensor(v) else v) for k, v in self.state[p].items()}
+                 for i, p in enumerate(self.all_params) if id(p) in own}
+        grp = {k: v for k, v in self.param_groups[0].items() if k != "params"}
+        grp["params"] = list(range(len(self.all_params)))
+        return {"state": state, "param_groups": [grp]}
+
     def load_state_dict(self, state_dict):
-        """stock layout in, flat buffers out: the moments are copied INTO the flat views"""
+        """stock layout in, flat buffers out: the moments are copied INTO the flat views.  Accepted: a state dict over
+        the model's full parameter list (this class's own state_dict(), torch.optim.Adam(model.parameters()), the
+        reference's checkpoints) or over exactly this optimizer's parameters; anything else raises."""
         sd = state_dict["state"]
         ids = [i for grp in state_dict["param_groups"] for i in grp["params"]]
-        plist = [p for grp in self.param_groups for p in grp["params"]]
+        own = [p for grp in self.param_groups for p in grp["params"]]
+        if len(ids) == len(self.all_params):
+            target = self.all_params
+        elif len(ids) == len(own):
+            target = own
+        else:
+            raise ValueError(f"optimizer state covers {len(ids)} parameters; expected {len(self.all_params)} (model order) "
+                             f"or {len(own)} (this optimizer's parameters)")
+        steps = set()
         with torch.no_grad():
-            for i, p in zip(ids, plist):
-                if i in sd:
-                    self.state[p]["exp_avg"].copy_(sd[i]["exp_avg"])
-                    self.state[p]["exp_avg_sq"].copy_(sd[i]["exp_avg_sq"])
-                    self.t = max(self.t, int(float(sd[i]["step"])))
+            for i, p in zip(ids, target):
+                if i not in sd or p not in self.state:
+                    continue              # no state saved / a parameter this optimizer does not train
+                for k in ("exp_avg", "exp_avg_sq"):
+                    if tuple(sd[i][k].shape) != tuple(p.shape):
+                        raise ValueError(f"optimizer state {k} of parameter {i} has shape {tuple(sd[i][k].shape)}, "
+                                         f"the parameter {tuple(p.shape)}")
+                    self.state[p][k].copy_(sd[i][k])
+                steps.add(int(float(sd[i]["step"])))
+        if len(steps) > 1:
+            raise ValueError(f"optimizer state holds different step counts {sorted(steps)}: the flat Adam keeps one")
+        if steps:
+            self.t = steps.pop()
         for grp, src in zip(self.param_groups, state_dict["param_groups"]):
             for k in ("lr", "betas", "eps", "weight_decay"):
                 grp[k] = src[k]

@@ -24,9 +24,8 @@ class Trainer:
         self.log_path = log_path
         self.global_step = 0
         self.optimizer = self.scheduler = None
-        # MIOpen "benchmark" (find) mode picks the fastest solver per conv shape (-8 % step time at B = 256)
-        # but searches for minutes on a cold find-db; bench.py turns it on only with the tuned db shipped
-        # under gloria-nlp-project_amd/miopen_db (see gloria.miopen_db)
+        # MIOpen "benchmark" (find) mode picks the fastest solver per conv shape (-8 % step time at B = 256); its
+        # per-process search is kept short by gloria.miopen_env (naive reference solvers off)
         self.miopen_benchmark = miopen_benchmark
         # data-parallel parity mode: BatchNorm statistics over the GLOBAL batch (torch SyncBatchNorm: one small
         # per-channel all-reduce per layer) - the reference oracle is single-device full-batch BN (SURVEY.md

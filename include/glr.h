@@ -161,8 +161,11 @@ int glr_pack_words(const void* words_emb, int in_dtype, const int32_t* sent_slot
  *   tile_first, order, tile_nsub   device int32 copies of the glr_plan_tiles outputs
  *   single_tile/n_single, pair_tile/n_pair (fwd), item_tile/n_items (bwd: the all_tile list)
  *                device int32 copies of the glr_plan_items outputs
+ *   n_long_pair  (fwd) how many LEADING entries of pair_tile are the two tiles of ONE 65..128-word sentence (the planner
+ *                lists multi-tile sentences first).  Those run the 8-wave pair kernel; the ordinary pairs (two whole
+ *                tiles) run one 4-wave workgroup per tile, two workgroups per CU (csrc/glr_local_attn_t1.hip).
  *   pair_desc    (fwd) device copy of the glr_plan_pair_desc output [n_pair][64]; required when n_pair > 0.  The
- *                pair kernel also needs S_eff < S_pad and expects gram[b] to carry ONES in row S_pad - 1, columns
+ *                pair kernels also need S_eff < S_pad and expects gram[b] to carry ONES in row S_pad - 1, columns
  *                r < S_eff (a padded region; glr_tile_gram writes it): the second contraction then delivers
  *                Z_w = sum_r e2[w, r] in output column S_pad - 1.  Every other kernel masks padded regions, so the
  *                same gram serves them and the backward.
@@ -203,8 +206,8 @@ int glr_pack_words(const void* words_emb, int in_dtype, const int32_t* sent_slot
 int glr_local_attn_fwd(const void* vt, const void* gram, const void* tp, const float* tnorm,
                        const int32_t* sent_slot0, const int32_t* cap_lens, const int32_t* tile_first,
                        const int32_t* order, const int32_t* tile_nsub, const int32_t* single_tile, int n_single,
-                       const int32_t* pair_tile, int n_pair, const int32_t* pair_desc, int n_tiles, int n_sent,
-                       int B_img, int D, int S_eff, float temp1, float temp2, float temp3, int agg, float eps,
+                       const int32_t* pair_tile, int n_pair, int n_long_pair, const int32_t* pair_desc, int n_tiles,
+                       int n_sent, int B_img, int D, int S_eff, float temp1, float temp2, float temp3, int agg, float eps,
                        float* sim, int ld_sim, float* lse, float* wstat, float* attn, const int64_t* attn_off,
                        int strip, int pair_only, int img_offset, float* amean, void* a1buf, int op_dtype, void* stream);
 
@@ -220,9 +223,11 @@ int glr_local_attn_bwd(const void* vt, const void* gram, const void* tp, const f
 
 /* K-tiling of the K1 operands (device, HBM-bound copy).  glr_local_attn_fwd / _bwd take vt, gram and tp in
  * the K-TILED layout: every block of `rows` rows (vt, gram: the S_pad rows of one image; tp: the 64 slots of one
- * tile) is stored as [row_bytes / 64][rows][64 bytes], i.e. the 64-byte K chunks of all rows of a block are
- * contiguous, which turns every LDS-DMA piece of the K1 streams into one contiguous 1-KiB read.
- *   src   row-major [n_blocks * rows][row_bytes]     dst  same size, tiled     row_bytes % 64 == 0
+ * tile) is stored as [row_bytes / 64] chunks of rows * 64 bytes, and inside a chunk FRAGMENT-MAJOR:
+ * [rows / 32][4 x 16-byte slot of the row's 64 bytes][32 rows][16 bytes].  The MFMA fragment one wave loads per k-step
+ * (32 rows x 2 slots) is then 1 KiB of contiguous memory - operands only one wave needs go straight to registers in
+ * whole lines - and an LDS-DMA piece of the K1 streams (16 rows x 4 slots) reads four 256-byte runs.
+ *   src   row-major [n_blocks * rows][row_bytes]     dst  same size, tiled     row_bytes % 64 == 0, rows % 32 == 0
  */
 int glr_tile_k(const void* src, void* dst, int rows, long long n_blocks, int row_bytes, void* stream);
 /* glr_tile_gram: K-tiling of the Gram matrices gram [B, S_pad, S_pad] (op_dtype) that also writes the ONES ROW the

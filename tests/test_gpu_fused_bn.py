@@ -177,3 +177,16 @@ def test_resnet_with_forked_block_outputs_trains(monkeypatch):
     worst = max(float((ga[n] - gb[n]).norm() / gb[n].norm()) for n in gb if float(gb[n].norm()) > 1e-4)
     print(f"[resnet forked vs plain] worst parameter-gradient relative difference {worst:.4f}; run-to-run {noise:.4f}")
     assert worst < max(3 * noise, 5e-2), (worst, noise)
+
+
+@pytest.mark.gpu
+def test_sync_batchnorm_never_takes_the_per_rank_kernels():
+    """nn.SyncBatchNorm has BatchNorm2d's attributes; the fused per-rank kernels must leave it to torch
+    (its statistics span the process group), exactly nn.BatchNorm2d is fused."""
+    from gloria.models import fused_bn
+    x = torch.randn(4, 64, 8, 8, device="cuda", dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    bn = torch.nn.BatchNorm2d(64).cuda().train()
+    sbn = torch.nn.SyncBatchNorm.convert_sync_batchnorm(torch.nn.BatchNorm2d(64)).cuda().train()
+    assert isinstance(sbn, torch.nn.SyncBatchNorm)
+    assert fused_bn._fusable(bn, x, None)
+    assert not fused_bn._fusable(sbn, x, None)

@@ -246,3 +246,58 @@ def test_flat_optimizer_step_equals_stock_amp_step_and_resumes(tmp_path):
     # identical weights, moments and buffers (asserted above); the encoders' library GEMMs / convolutions (stream-K,
     # split reductions) are not bitwise reproducible between two model instances, hence a bf16-level band
     np.testing.assert_allclose(l1, l2, rtol=2e-3)
+
+
+def test_optimizer_state_crosses_between_stock_and_flat_adam_by_parameter(tmp_path):
+    """the flat optimizer leaves the (never-reached) BERT pooler out, stock Adam keeps it; text_encoder is
+    registered before img_encoder, so a positional mapping would land every later moment two parameters late.
+    Stock -> flat and flat -> stock resumes must map the moments BY PARAMETER; a state dict of a foreign size raises."""
+    from gloria import builder
+    from gloria.config import pretrain_config
+    from gloria.datasets.synthetic import make_batch
+    from gloria.trainer import Trainer
+    B = 8
+
+    def make(flat, seed):
+        torch.manual_seed(seed)
+        c = pretrain_config("imagenome", batch_size=B)
+        c.set_path("model.text.bert_config", dict(num_hidden_layers=2, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0))
+        model = builder.build_lightning_model(c, builder.build_data_module(c))
+        tr = Trainer(c, device="cuda:0", precision="bf16", flat_optimizer=flat)
+        tr.setup(model)
+        model.train()
+        return tr, model
+
+    def moments(tr, model):
+        out = {}
+        for n, p in model.named_parameters():
+            st = tr.optimizer.state.get(p)
+            if st and "exp_avg" in st and "pooler" not in n:
+                out[n] = (st["exp_avg"].float().cpu().clone(), st["exp_avg_sq"].float().cpu().clone())
+        return out
+
+    batch = make_batch(B, seed=77)
+    for src_flat in (False, True):
+        tr, model = make(src_flat, 5)
+        for i in range(2):
+            tr.training_step(model, batch, i)
+        ck = tmp_path / f"src_{int(src_flat)}.ckpt"
+        tr.save_checkpoint(model, str(ck))
+        n_saved = len(torch.load(ck, map_location="cpu", weights_only=True)["optimizer_states"][0]["param_groups"][0]["params"])
+        assert n_saved == len([p for p in model.parameters() if p.requires_grad])      # the reference layout: every parameter
+        want = moments(tr, model)
+        tr2, m2 = make(not src_flat, 6)
+        tr2.resume(m2, str(ck))
+        got = moments(tr2, m2)
+        assert set(want) == set(got) and len(want) > 300
+        for n in want:
+            np.testing.assert_allclose(got[n][0].numpy(), want[n][0].numpy(), rtol=0, atol=0, err_msg=n)
+            np.testing.assert_allclose(got[n][1].numpy(), want[n][1].numpy(), rtol=0, atol=0, err_msg=n)
+        if not src_flat:
+            assert tr2.optimizer.t == 2
+    # a state dict that is neither over the model's parameters nor over the optimizer's own is refused
+    tr, model = make(True, 5)
+    sd = tr.optimizer.state_dict()
+    sd["param_groups"][0]["params"] = sd["param_groups"][0]["params"][:-3]
+    with pytest.raises(ValueError):
+        tr.optimizer.load_state_dict(sd)
