@@ -307,6 +307,7 @@ def main():
     from gloria import miopen_env
     from gloria.datasets.synthetic import make_batch
     from gloria.loss import gloria_loss as GL
+    from gloria.models import gloria_model as GM
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
@@ -406,7 +407,7 @@ def main():
                        "tokens": 97, "caption_lengths": args.lengths, "miopen_find_mode": bool(use_find),
                        "first_step_s": first_step_s, "train_flags": bool(args.train_flags),
                        "world_size_seen": torch.distributed.get_world_size() if dctx else 1,
-                       "encoder_streams": int(getattr(trainer, "encoder_streams", -1)),
+                       "encoder_streams": 2 if GM.ENCODER_STREAMS else 1,
                        "kernel_launches_per_step": launches, "sum_cap_lens": cap_lens_sum,
                        "parallelism": f"dp{world}" + (" (text-embedding all-gather + grad all-reduce, RCCL)" if world > 1 else ""),
                        "final_loss": float(loss)},

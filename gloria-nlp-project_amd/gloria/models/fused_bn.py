@@ -17,7 +17,9 @@ from .. import _native as N
 
 ENABLED = os.environ.get("GLR_FUSED_BN", "1") != "0"
 
-_WS = {}            # device index -> fp32 workspace for the partial sums (all launches of a device share one stream order)
+# (device index, stream) -> fp32 workspace for the partial sums.  A workspace is only ever touched by launches of ONE
+# stream, so stream order alone makes its reuse safe - also when the two encoders run on two streams.
+_WS = {}
 
 
 _WS_FLOATS = {}     # (rows, channels) -> glr_bn_workspace_floats: one ctypes call per shape, not per launch (host time)
@@ -27,10 +29,11 @@ def _workspace(dev, R, c):
     n = _WS_FLOATS.get((R, c))
     if n is None:
         n = _WS_FLOATS[(R, c)] = int(N.lib().glr_bn_workspace_floats(R, c))
-    ws = _WS.get(dev.index)
+    key = (dev.index, N.stream())
+    ws = _WS.get(key)
     if ws is None or ws.numel() < n:
         ws = torch.empty(max(n, 1 << 20), dtype=torch.float32, device=dev)
-        _WS[dev.index] = ws
+        _WS[key] = ws
     return ws
 
 

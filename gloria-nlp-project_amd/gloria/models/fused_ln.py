@@ -19,7 +19,7 @@ import torch.nn.functional as F
 from .. import _native as N
 
 ENABLED = os.environ.get("GLR_FUSED_LN", "1") != "0"
-_WS = {}
+_WS = {}            # (device index, stream) -> fp32 workspace: launches of one stream only (see fused_bn)
 
 
 _WS_FLOATS = {}
@@ -29,10 +29,11 @@ def _workspace(dev, R, H):
     n = _WS_FLOATS.get((R, H))
     if n is None:
         n = _WS_FLOATS[(R, H)] = int(N.lib().glr_ln_workspace_floats(R, H))
-    ws = _WS.get(dev.index)
+    key = (dev.index, N.stream())
+    ws = _WS.get(key)
     if ws is None or ws.numel() < n:
         ws = torch.empty(max(n, 1 << 21), dtype=torch.float32, device=dev)
-        _WS[dev.index] = ws
+        _WS[key] = ws
     return ws
 
 

@@ -46,7 +46,9 @@ class PositionEmbeddings(nn.Module):
         return torch.cat(embs + [pad], -1)
 
 
-_ENCODER_STREAMS = os.environ.get("GLR_ENCODER_STREAMS", "1") != "0"     # two-stream encoders (A/B switch)
+# two-stream encoders.  A plain module attribute read at every forward: tests and tools flip it
+# (`gloria_model.ENCODER_STREAMS = False`) to compare the two paths in one process.
+ENCODER_STREAMS = os.environ.get("GLR_ENCODER_STREAMS", "1") != "0"
 _SIDE = {}
 
 
@@ -191,14 +193,17 @@ class GLoRIA(nn.Module):
         return shared + share
 
     def forward(self, x):
-        if _ENCODER_STREAMS and x["imgs"].is_cuda and torch.is_grad_enabled() and not (self.dist is not None and self.dist.active):
+        if ENCODER_STREAMS and x["imgs"].is_cuda and torch.is_grad_enabled():
             # The two encoders are independent: the text encoder runs on a side HIP stream (autograd runs its backward
             # there too), so its many short kernels fill the gaps between the image encoder's (88.6 -> 81 ms per step).
-            # Single-process training only: the data-parallel reducer gathers gradient buckets from its hooks on one
-            # stream and would need cross-stream events first.
+            # Data parallel too: the reducer orders its bucket launches behind every stream that produced one of the
+            # bucket's gradients (gloria.dist.GradReducer._join_streams).
             cur = torch.cuda.current_stream()
             side = _side_stream(x["imgs"].device)
             side.wait_stream(cur)
+            for k in ("caption_ids", "attention_mask", "token_type_ids"):
+                if torch.is_tensor(x[k]):
+                    x[k].record_stream(side)          # allocated on the main stream, read on the side stream
             with torch.cuda.stream(side):
                 text_emb_l, text_emb_g, sents = self.text_encoder_forward(
                     x["caption_ids"], x["attention_mask"], x["token_type_ids"])

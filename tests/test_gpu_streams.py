@@ -1,0 +1,109 @@
+"""The two-stream encoder path (text encoder on a side HIP stream, forward and - through autograd - backward) against the
+single-stream path: the SAME seeded bf16 training step (12-layer BERT, 64 pairs, dropout ON - the production step) must
+give the same loss, BatchNorm running statistics and gradients whichever path runs, in single-process training and on the
+data-parallel path (bucketed reducer, here on a single-rank RCCL group).  Nothing in the maths depends on the stream, and
+the dropout keys are drawn on the host in program order, so the only differences allowed are those of the library GEMMs /
+convolutions, which are not bitwise reproducible between two runs (split reductions): bf16-level bands, stated below."""
+
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+B = 64
+
+
+def _run(streams, dctx):
+    from gloria import builder
+    from gloria.config import pretrain_config
+    from gloria.datasets.synthetic import make_batch
+    from gloria.models import gloria_model as GM
+    from gloria.trainer import Trainer
+    GM.ENCODER_STREAMS = bool(streams)
+    cfg = pretrain_config("imagenome", batch_size=B)                       # BERT-base, 12 layers, dropout 0.1
+    torch.manual_seed(31)
+    model = builder.build_lightning_model(cfg, builder.build_data_module(cfg))
+    tr = Trainer(cfg, device="cuda:0", precision="bf16", dist_ctx=dctx)
+    tr.setup(model)
+    model.train()
+    batch = make_batch(B, seed=8, lengths="words")
+    torch.manual_seed(17)                                                  # the dropout keys of both runs
+    torch.cuda.manual_seed(17)
+    loss = float(tr.training_step(model, batch, 0))
+    torch.cuda.synchronize()
+    grads = {}
+    if tr.reducer is not None:                 # data parallel: the gathered + reduced flat gradient buffers
+        for k, g in enumerate(tr.optimizer.groups):
+            grads[f"flat{k}"] = g.grad.float().cpu()
+    else:
+        for n, p in model.named_parameters():
+            if p.grad is not None:
+                grads[n] = p.grad.float().cpu()
+    bn = {n: b.float().cpu().clone() for n, b in model.named_buffers() if "running_" in n}
+    loss2 = float(tr.training_step(model, batch, 1))                       # carries step 0's update of every parameter
+    return loss, loss2, grads, bn
+
+
+def _compare(a, b):
+    # losses: a bf16 forward of two non-bitwise-reproducible library runs
+    np.testing.assert_allclose(a[0], b[0], rtol=2e-3)
+    np.testing.assert_allclose(a[1], b[1], rtol=2e-2)          # after one Adam update (sign-like: amplifies bf16 noise)
+    assert set(a[2]) == set(b[2]) and len(a[2]) > 0
+    num = sum(float(((a[2][k] - b[2][k]) ** 2).sum()) for k in a[2])
+    den = sum(float((a[2][k] ** 2).sum()) for k in a[2])
+    assert den > 0 and (num / den) ** 0.5 < 3e-2               # relative Frobenius distance of ALL gradients
+    for k in a[2]:                                             # and no tensor is missing its side-stream share
+        na, nb = float(a[2][k].norm()), float(b[2][k].norm())
+        assert abs(na - nb) <= 0.25 * max(na, nb) + 1e-6, k
+    assert set(a[3]) == set(b[3]) and len(a[3]) >= 100
+    for k in a[3]:                                             # image encoder: same stream, same kernels in both runs
+        np.testing.assert_allclose(a[3][k].numpy(), b[3][k].numpy(), rtol=2e-3, atol=1e-5, err_msg=k)
+
+
+def test_two_stream_encoders_equal_single_stream():
+    from gloria.models import gloria_model as GM
+    keep = GM.ENCODER_STREAMS
+    try:
+        one = _run(False, None)
+        two = _run(True, None)
+    finally:
+        GM.ENCODER_STREAMS = keep
+    _compare(one, two)
+
+
+def test_two_stream_encoders_under_the_data_parallel_reducer(monkeypatch):
+    """the reducer joins the streams that produced a bucket's gradients before it gathers and all-reduces the bucket
+    (gloria.dist.GradReducer._join_streams): same flat gradient buffers with one stream and with two"""
+    import torch.distributed as dist
+    from gloria import dist as gdist
+    from gloria.models import gloria_model as GM
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    for k, v in dict(GLR_FORCE_DIST="1", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+                     MASTER_PORT=str(port)).items():
+        monkeypatch.setenv(k, v)
+    keep = GM.ENCODER_STREAMS
+    try:
+        dctx = gdist.init_from_env("nccl")
+        one = _run(False, dctx)
+        two = _run(True, dctx)
+    finally:
+        GM.ENCODER_STREAMS = keep
+        if dist.is_initialized():
+            dist.destroy_process_group()
+    _compare(one, two)
+
+
+def test_fused_workspaces_are_per_stream():
+    from gloria.models import fused_bn, fused_ln
+    dev = torch.device("cuda", 0)
+    side = torch.cuda.Stream(device=dev)
+    a = fused_bn._workspace(dev, 1024, 64)
+    with torch.cuda.stream(side):
+        b = fused_bn._workspace(dev, 1024, 64)
+        c = fused_ln._workspace(dev, 1024, 768)
+    d = fused_ln._workspace(dev, 1024, 768)
+    assert a.data_ptr() != b.data_ptr() and c.data_ptr() != d.data_ptr()
+    assert fused_bn._workspace(dev, 1024, 64).data_ptr() == a.data_ptr()
