@@ -1273,8 +1273,13 @@ __global__ void __launch_bounds__(NTHR) k_local_attn_pw(LaParams p) {
 // P = (beta a2)^T a2 GEMM).  Empty word slots have zero scalars: their rows of every output are exact zeros.
 // A1IN: the forward pair kernel handed over a1 (LaParams::a1buf, fp16 pairs in this kernel's own register order): no
 // score stream; the score itself, needed for -alpha s, is lse + log(a1).
-template <typename O, bool A1IN>
+// AUX (with A1IN only): the extra gradient inputs `damean` (word-mean attention rows: regularisers) and `dattn` (diagonal
+// attention maps: attention supervision), g[w, r] = damean[b, sentence(w), r] / n_words (+ dattn[w, r] on the diagonal
+// pair): da2 gains g, i.e. the accumulator starts at -(alpha s + g), and kappa_w gains sum_r a2[w, r] g[w, r].  The
+// damean rows of the pair's sentences are parked in LDS beside the lse rows (the P1 ring is not used with A1IN).
+template <typename O, bool A1IN, bool AUX = false>
 __global__ void __launch_bounds__(NTHR) k_local_attn_pw_bwd(LaParams p) {
+  static_assert(A1IN || !AUX, "the extra gradient inputs ride on the a1 hand-over variant");
   constexpr int ESZ = O::ESZ, CB = CHB;
   constexpr int SP = GLR_MAX_SPAD;
   constexpr int NRB = SP / 32;
@@ -1322,6 +1327,8 @@ __global__ void __launch_bounds__(NTHR) k_local_attn_pw_bwd(LaParams p) {
   int* misc = seg_sent + PW_MAXSEG;                              // [16..79] descriptor
   float4* w4 = reinterpret_cast<float4*>(misc + 80);             // [2 * TW] (1/Z, beta, alpha, kappa) per word slot
   float* zero = reinterpret_cast<float*>(w4 + 2 * TW);           // [SP] neutral second table row
+  [[maybe_unused]] float* kred = zero + SP;                      // AUX: [8][2 * TW] partial sums of a2 g per word
+  [[maybe_unused]] float* gt = reinterpret_cast<float*>(smem + p.off_img);   // AUX: [PW_MAXSEG][SP] damean / n (P2 only)
 
   const size_t rowbytes1 = (size_t)D * ESZ, rowbytes2 = (size_t)SP * ESZ;
   const unsigned char* vt_b = p.vt + (size_t)b * SP * rowbytes1;
@@ -1339,6 +1346,7 @@ __global__ void __launch_bounds__(NTHR) k_local_attn_pw_bwd(LaParams p) {
     tn = p.tnorm[slot];
   }
   if (tid < SP) zero[tid] = 0.f;
+  if (tid < 3) misc[tid] = 0;
   __syncthreads();
   const int NS = dsc[0];
   const bool long_pair = dsc[1] != 0;
@@ -1348,6 +1356,7 @@ __global__ void __launch_bounds__(NTHR) k_local_attn_pw_bwd(LaParams p) {
     seg_w0[tid] = w0;
     seg_n[tid] = n;
     for (int w = 0; w < n; ++w) wsegb[w0 + w] = (signed char)tid;
+    if (AUX && sent == p.img_offset + b) { misc[1] = w0; misc[2] = n; }
   }
   __syncthreads();
   // second round trip, issued here and consumed behind the score stream: dsim / sim of the slot's sentence, and the
@@ -1371,6 +1380,14 @@ __global__ void __launch_bounds__(NTHR) k_local_attn_pw_bwd(LaParams p) {
 
 #pragma unroll
   for (int i = 0; i < PW_MAXSEG * SP / NTHR; ++i) lt[tid + i * NTHR] = lpre[i] * LOG2E;
+  if constexpr (AUX) {
+#pragma unroll
+    for (int i = 0; i < PW_MAXSEG * SP / NTHR; ++i) {
+      const int e = tid + i * NTHR, s2 = e / SP, r = e - s2 * SP;
+      gt[e] = (p.damean != nullptr && s2 < NS && r < p.S_eff)
+                  ? p.damean[((size_t)b * p.n_sent + dsc[8 + s2]) * SP + r] / (float)dsc[24 + s2] : 0.f;
+    }
+  }
   if (tid < 2 * TW) {
     // per-word scalars from dsim and the forward's saved statistics (the single-tile kernel's formulas)
     float al = 0.f, be = 0.f, ka = 0.f, zi = 0.f, ga = 0.f;
@@ -1426,25 +1443,52 @@ __global__ void __launch_bounds__(NTHR) k_local_attn_pw_bwd(LaParams p) {
   // ================= P2 =================
   if (!GLR_SKIP(4)) {
     float lc[3] = {0.f, 0.f, 0.f};
+    [[maybe_unused]] float gc[3] = {0.f, 0.f, 0.f};          // AUX: damean / n of the current run's sentence
+    // AUX: gradient of the diagonal pair's attention map (attention supervision), per (word, region); at most ONE
+    // workgroup per image holds the diagonal sentence
+    [[maybe_unused]] const int dw0 = AUX ? misc[1] : 0, dn = (AUX && p.dattn != nullptr) ? misc[2] : 0;
+    [[maybe_unused]] const int sout = p.S_eff - p.strip;
+    [[maybe_unused]] const float* dmap = dn > 0 ? p.dattn + p.attn_off[p.img_offset + b] - p.strip : nullptr;
+    [[maybe_unused]] float* kredt = kred + (wg * 2 + ((lane >> 4) & 1)) * (2 * TW) + t * TW + 4 * h;
 #pragma unroll
     for (int blk = 0; blk < 2; ++blk) {
       f32x16(&acc)[3] = blk == 0 ? acc0 : acc1;
       unsigned(&a1k)[3][8] = blk == 0 ? a1k0 : a1k1;
       [[maybe_unused]] float a1e[3] = {0.f, 0.f, 0.f};
+      [[maybe_unused]] float zq[4];                // reduced across lanes every four rows (interleaved DPP chains)
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         const int k = blk * 16 + q;
         const int row = blk * 32 + (q & 3) + 8 * (q >> 2);
         if (GLR_SBIT(STANY, k)) {
           const bool mine = (STh >> k) & 1;
-          const float* src = lt + (long_pair ? 0 : max(GLR_SGK(k), 0)) * SP + rbase;
+          const int srow = (long_pair ? 0 : max(GLR_SGK(k), 0)) * SP + rbase;
+          const float* src = lt + srow;
 #pragma unroll
           for (int j = 0; j < 3; ++j) {
             const float l2 = src[128 * j];
             lc[j] = mine ? l2 : lc[j];
+            if constexpr (AUX) {
+              const float g2 = gt[srow + 128 * j];
+              gc[j] = mine ? g2 : gc[j];
+            }
           }
         }
         const float4 w = w4t[row];
+        [[maybe_unused]] float ge[3] = {gc[0], gc[1], ok2 * gc[2]};
+        if constexpr (AUX) {
+          if (__builtin_expect(dn > 0, 0)) {
+            const int wd = t * TW + row + 4 * h - dw0;
+            if (wd >= 0 && wd < dn) {
+#pragma unroll
+              for (int j = 0; j < 3; ++j) {
+                const int region = rbase + 128 * j;
+                if (region >= p.strip && region < p.S_eff) ge[j] += dmap[(size_t)wd * sout + region];
+              }
+            }
+          }
+        }
+        [[maybe_unused]] float zacc = 0.f;
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
           float a1, sc;
@@ -1465,13 +1509,36 @@ __global__ void __launch_bounds__(NTHR) k_local_attn_pw_bwd(LaParams p) {
             if (q & 1) asm volatile("v_cvt_pkrtz_f16_f32 %0, %1, %2" : "=v"(a1k[j][q >> 1]) : "v"(a1e[j]), "v"(a1));
             else a1e[j] = a1;
           }
-          acc[j][q] = -w.z * sc;
+          if constexpr (AUX) {
+            acc[j][q] = __builtin_fmaf(-w.z, sc, -ge[j]);       // da2 = (alpha s - beta u) + g
+            zacc = __builtin_fmaf(a2, ge[j], zacc);             // kappa gains sum_r a2 g (softmax-over-regions backward)
+          } else {
+            acc[j][q] = -w.z * sc;
+          }
           asm volatile("" : "+v"(acc[j][q]));                   // computed HERE (not sunk to its use behind the barrier)
+        }
+        if constexpr (AUX) {
+          zq[q & 3] = zacc;
+          if ((q & 3) == 3) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const float z = row_sum16(zq[i]);
+              if ((lane & 15) == 15) kredt[blk * 32 + i + 8 * (q >> 2)] = z;
+            }
+          }
         }
       }
     }
   }
   __syncthreads();                              // images complete; lt is dead: the P3 ring takes its place
+  if constexpr (AUX) {
+    if (tid < 2 * TW) {                         // read by pass A behind the barriers of the P3 stream
+      float kg = 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) kg += kred[k * (2 * TW) + tid];
+      w4[tid].w += kg;
+    }
+  }
   GLR_STAMP2(3);
 
   // ================= P3: acc += (beta a2) . G^T =================
@@ -1689,7 +1756,8 @@ int launch_pair(LaParams& p, int op_dtype, void* stream) {
 
 int launch_pair_bwd(LaParams& p, int op_dtype, void* stream) {
   if (op_dtype != GLR_BF16 || p.S_pad != GLR_MAX_SPAD) return GLR_EINVAL;
-  if (p.damean != nullptr || p.dattn != nullptr) return GLR_EINVAL;   // the extra gradient inputs take the single-tile kernel
+  const bool aux = p.damean != nullptr || p.dattn != nullptr;
+  if (aux && p.a1buf == nullptr) return GLR_EINVAL;   // without the a1 hand-over the extra gradient inputs take the single-tile kernel
   const int lds = carve_pair(p, op_dtype, p.S_pad);
   // lse table behind the P1 ring, in front of the small area
   if (lds > 160 * 1024 || NBUF * (2 * TW + p.S_pad) * CHB + PW_MAXSEG * p.S_pad * 4 > p.off_small) return GLR_EINVAL;
@@ -1701,7 +1769,11 @@ int launch_pair_bwd(LaParams& p, int op_dtype, void* stream) {
 #ifdef GLR_ABLATE
   { const char* e = getenv("GLR_K1_DBG"); p.dbg = e ? atoi(e) : 0; }
 #endif
-  if (p.a1buf != nullptr) {
+  if (aux) {
+    static GlrLdsAttr la_b2;
+    if (glr_ensure_lds(la_b2, (const void*)k_local_attn_pw_bwd<OpBF16, true, true>, lds) != GLR_OK) return GLR_ELAUNCH;
+    hipLaunchKernelGGL((k_local_attn_pw_bwd<OpBF16, true, true>), dim3(grid), dim3(NTHR), lds, (hipStream_t)stream, p);
+  } else if (p.a1buf != nullptr) {
     static GlrLdsAttr la_b1;
     if (glr_ensure_lds(la_b1, (const void*)k_local_attn_pw_bwd<OpBF16, true>, lds) != GLR_OK) return GLR_ELAUNCH;
     hipLaunchKernelGGL((k_local_attn_pw_bwd<OpBF16, true>), dim3(grid), dim3(NTHR), lds, (hipStream_t)stream, p);

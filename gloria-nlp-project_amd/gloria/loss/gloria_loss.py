@@ -252,7 +252,9 @@ class LocalSimFn(torch.autograd.Function):
             bwd_range = _Range("k1_bwd_op")
             bwd_range.__enter__()
             with _Range("k1_bwd"):
-                mode = "all_single" if (dam is not None or dat is not None) else True
+                # the extra gradient inputs (regulariser rows / attention maps) ride on the pair kernel's a1 hand-over
+                # variant; without the hand-over buffer every tile goes through the single-tile kernel
+                mode = "all_single" if ((dam is not None or dat is not None) and a1buf is None) else True
                 N.check(L.glr_local_attn_bwd(*_k1_args(plan, vt_t, gram_t, tp_t, tnorm, B, D, s_eff, o, mode), N.ptr(sim),
                                              N.ptr(g), plan.n_sent, N.ptr(lse), N.ptr(wstat), N.ptr(dam), N.ptr(dat),
                                              N.ptr(dat_off), strip, o.img_offset, N.ptr(xout), N.ptr(aout), N.ptr(baout),

@@ -59,6 +59,20 @@ def _side_stream(dev):
     return s
 
 
+class _ImagePath(nn.Module):
+    """image_encoder_forward as a tensor -> (local, global) module: the callable torch.cuda.make_graphed_callables
+    captures (GLoRIA.enable_image_graph)."""
+
+    def __init__(self, img_encoder):
+        super().__init__()
+        self.img_encoder = img_encoder
+
+    def forward(self, imgs):
+        img_feat_g, img_emb_l = self.img_encoder(imgs, get_local=True)
+        img_emb_g, img_emb_l = self.img_encoder.generate_embeddings(img_feat_g, img_emb_l)
+        return img_emb_l, img_emb_g
+
+
 class GLoRIA(nn.Module):
     def __init__(self, cfg):
         super().__init__()
@@ -87,13 +101,40 @@ class GLoRIA(nn.Module):
         self.temp1, self.temp2, self.temp3 = g.temp1, g.temp2, g.temp3
         self.batch_size = cfg.train.batch_size
         self.dist = None                        # set by the trainer for data-parallel runs
+        self._img_graph, self._img_graph_shape = None, None      # set by enable_image_graph()
         self.ixtoword = None                    # reference attribute (:79); strings live in text_encoder.vocab
 
     # ------------------------------------------------------------------ encoders (ref :81-103)
     def text_encoder_forward(self, caption_ids, attention_mask, token_type_ids):
         return self.text_encoder(caption_ids, attention_mask, token_type_ids)
 
+    def enable_image_graph(self, sample_imgs, autocast_dtype=None, warmup=3):
+        """Capture the image encoder's forward AND backward (static shapes, no dropout, no data-dependent allocation:
+        ~500 of the step's ~1150 launches) into two hipGraphs (torch.cuda.make_graphed_callables).  The 32-pair
+        data-parallel step is bound by HOST time; a replay costs the host two launches, and with the text encoder on its
+        side stream the host queues BERT while the device replays the image graph.  The text encoder stays eager: its
+        embedding backward replays with capture-time sizes (round 1's aperture violation), and its dropout keys come
+        from the host.  BatchNorm buffers are restored after the warm-up passes, so the first real step sees the
+        statistics an eager run would."""
+        if not sample_imgs.is_cuda or self.position_embeddings is not None or self.image_transformer is not None:
+            return False
+        path = _ImagePath(self.img_encoder)
+        path.train(self.training)
+        keep = {k: v.detach().clone() for k, v in self.img_encoder.named_buffers()}
+        ctx = torch.autocast("cuda", dtype=autocast_dtype, cache_enabled=False) if autocast_dtype is not None \
+            else torch.autocast("cuda", enabled=False)
+        with ctx:
+            graphed = torch.cuda.make_graphed_callables(path, (sample_imgs.detach().clone(),), num_warmup_iters=warmup)
+        with torch.no_grad():
+            for k, v in self.img_encoder.named_buffers():
+                v.copy_(keep[k])
+        self._img_graph, self._img_graph_shape = graphed, (tuple(sample_imgs.shape), sample_imgs.dtype)
+        return True
+
     def image_encoder_forward(self, imgs):
+        if (self._img_graph is not None and self.training and torch.is_grad_enabled()
+                and (tuple(imgs.shape), imgs.dtype) == self._img_graph_shape):
+            return self._img_graph(imgs)
         img_feat_g, img_emb_l = self.img_encoder(imgs, get_local=True)
         img_emb_g, img_emb_l = self.img_encoder.generate_embeddings(img_feat_g, img_emb_l)
         b, c, h, w = img_emb_l.shape

@@ -13,7 +13,7 @@ import torch
 
 class Trainer:
     def __init__(self, cfg, device="cuda", precision=None, dist_ctx=None, log_path=None, miopen_benchmark=False,
-                 sync_bn=False, flat_optimizer=None):
+                 sync_bn=False, flat_optimizer=None, graph_image_encoder=None):
         self.cfg = cfg
         self.device = torch.device(device)
         prec = precision if precision is not None else cfg.lightning.trainer.precision
@@ -31,6 +31,12 @@ class Trainer:
         # per-channel all-reduce per layer) - the reference oracle is single-device full-batch BN (SURVEY.md
         # section 7); the default keeps per-rank statistics (speed mode)
         self.sync_bn = bool(sync_bn)
+        # hipGraph capture of the image encoder's forward + backward at the first training step (GLoRIA.enable_image_graph);
+        # GLR_GRAPH_IMG=0/1 overrides.  Off with SyncBatchNorm (a collective inside the capture).
+        if graph_image_encoder is None:
+            graph_image_encoder = os.environ.get("GLR_GRAPH_IMG", "0") != "0"
+        self.graph_image_encoder = bool(graph_image_encoder) and not self.sync_bn
+        self._graph_tried = False
         # bf16 runs on the GPU keep fp32 master weights + bf16 shadows in flat buffers and do clip + Adam in three
         # launches (gloria/optim.py); GLR_FLAT_OPTIMIZER=0 or flat_optimizer=False keeps torch's fused Adam + autocast casts
         if flat_optimizer is None:
@@ -84,6 +90,9 @@ class Trainer:
     # ------------------------------------------------------------------ one optimisation step
     def training_step(self, model, batch, batch_idx=0):
         batch = self.to_device(batch)
+        if self.graph_image_encoder and not self._graph_tried and self.device.type == "cuda" and self.autocast_dtype is not None:
+            self._graph_tried = True          # once: the batch shape is static in training (drop_last loaders)
+            model.gloria.enable_image_graph(batch["imgs"], self.autocast_dtype)
         ctx = torch.autocast(self.device.type, dtype=self.autocast_dtype) if self.autocast_dtype else _Null()
         with ctx:
             out = model.training_step(batch, batch_idx)

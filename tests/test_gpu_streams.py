@@ -107,3 +107,43 @@ def test_fused_workspaces_are_per_stream():
     d = fused_ln._workspace(dev, 1024, 768)
     assert a.data_ptr() != b.data_ptr() and c.data_ptr() != d.data_ptr()
     assert fused_bn._workspace(dev, 1024, 64).data_ptr() == a.data_ptr()
+
+
+def test_graphed_image_encoder_equals_eager():
+    """hipGraph replay of the image encoder's forward + backward (GLoRIA.enable_image_graph) against the eager path:
+    same seeded bf16 step, same loss / gradients / BatchNorm statistics within the bands of `_compare`; the BatchNorm
+    buffers after capture (three warm-up passes run inside it) must be exactly the pre-capture ones."""
+    from gloria import builder
+    from gloria.config import pretrain_config
+    from gloria.datasets.synthetic import make_batch
+    from gloria.trainer import Trainer
+
+    def run(graph):
+        cfg = pretrain_config("imagenome", batch_size=B)
+        torch.manual_seed(31)
+        model = builder.build_lightning_model(cfg, builder.build_data_module(cfg))
+        tr = Trainer(cfg, device="cuda:0", precision="bf16", graph_image_encoder=graph)
+        tr.setup(model)
+        model.train()
+        batch = make_batch(B, seed=8, lengths="words")
+        before = {n: b.float().cpu().clone() for n, b in model.named_buffers() if "running_" in n or "num_batches" in n}
+        if graph:
+            dev_batch = tr.to_device(batch)
+            assert model.gloria.enable_image_graph(dev_batch["imgs"], torch.bfloat16)
+            tr._graph_tried = True
+            for n, b in model.named_buffers():
+                if n in before:
+                    assert torch.equal(b.float().cpu(), before[n]), n
+        torch.manual_seed(17)
+        torch.cuda.manual_seed(17)
+        loss = float(tr.training_step(model, batch, 0))
+        torch.cuda.synchronize()
+        assert (model.gloria._img_graph is not None) == bool(graph)
+        grads = {n: p.grad.float().cpu() for n, p in model.named_parameters() if p.grad is not None}
+        bn = {n: b.float().cpu().clone() for n, b in model.named_buffers() if "running_" in n}
+        loss2 = float(tr.training_step(model, batch, 1))
+        nbt = [int(b) for n, b in model.named_buffers() if n.endswith("bn1.num_batches_tracked")][:1]
+        assert nbt == [2]
+        return loss, loss2, grads, bn
+
+    _compare(run(False), run(True))
