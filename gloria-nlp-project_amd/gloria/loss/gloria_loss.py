@@ -222,7 +222,7 @@ class LocalSimFn(torch.autograd.Function):
         L = N.lib()
         dev = img_features.device
         B, D = img_features.shape[:2]
-        d_img = torch.zeros(B, D, s_eff - shift, dtype=torch.float32, device=dev)
+        d_img = None              # allocated by whoever contributes first (the common case needs no fp32 staging at all)
         d_words = torch.zeros(words_emb.shape, dtype=torch.float32, device=dev)
         d_na = None if no_attn_vec is None else torch.zeros(D, dtype=torch.float32, device=dev)
 
@@ -265,12 +265,22 @@ class LocalSimFn(torch.autograd.Function):
             x2d = xout.view(ns, B * s_pad)
             dtp = (x2d @ vt.view(B * s_pad, D)).float() - gamma.sum(0).unsqueeze(1) * tp.float()      # [ns, D]
             P = torch.bmm(baout.transpose(1, 2), aout)                                                 # [B, S, S], baout = beta a2
-            dvt = (x2d.t() @ tp).view(B, s_pad, D).float() - torch.bmm(P, vt).float()                 # [B, S, D]
+            # dvt = X^T tp - P vt: the second product accumulates onto the first inside the GEMM (one rounding of the
+            # fp32 sum to the operand dtype instead of two rounded products subtracted by three elementwise passes)
+            dvt = torch.baddbmm((x2d.t() @ tp).view(B, s_pad, D), P, vt, alpha=-1.0)                   # [B, S, D]
             si, wi, slot = plan.word_index(dev)
             d_words.permute(0, 2, 1)[si, wi + o.word_start] = dtp[slot]
-            d_img += dvt[:, shift:s_eff].transpose(1, 2)
+            cl = (img_features.dim() == 4 and img_features.dtype == dvt.dtype and not img_features.is_contiguous()
+                  and img_features.is_contiguous(memory_format=torch.channels_last))
+            if cl and not (need_attn and not hip_attn) and not need_wctx:
+                # channels-last features ARE [B, S, D] in memory: the packed-region gradient, minus the no-attention row
+                # and the padding, is the feature gradient - a strided view, no transpose / zero-fill / cast pass
+                H_, W_ = img_features.shape[2], img_features.shape[3]
+                d_img = dvt[:, shift:s_eff].unflatten(1, (H_, W_)).permute(0, 3, 1, 2)
+            else:
+                d_img = dvt[:, shift:s_eff].transpose(1, 2).float()
             if d_na is not None:
-                d_na += dvt[:, 0].sum(0)
+                d_na += dvt[:, 0].float().sum(0)
             bwd_range.__exit__()
 
         need_attn = need_attn and not hip_attn
@@ -293,10 +303,12 @@ class LocalSimFn(torch.autograd.Function):
                     ctxv = torch.einsum("bdr,bwr->bdw", V, a2)
                     loss = loss + (ctxv * dwctx[:, :, :ctxv.shape[2]].float()).sum()
                 loss.backward()
-            d_img += vc.grad
+            d_img = vc.grad if d_img is None else d_img.float() + vc.grad
             d_words += words.grad
             if na is not None and na.grad is not None:
                 d_na += na.grad
+        if d_img is None:
+            d_img = torch.zeros(img_features.shape, dtype=img_features.dtype, device=dev)
         return (d_img.reshape(img_features.shape).to(img_features.dtype), d_words.to(words_emb.dtype),
                 None if d_na is None else d_na.to(no_attn_vec.dtype), None, None)
 

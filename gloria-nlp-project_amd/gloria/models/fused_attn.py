@@ -5,8 +5,12 @@
 `self_attention(q, k, v, key_mask, n_heads, p, training)` takes the [B, L, H] outputs of the query / key / value Linears
 as they are and returns the context in the same layout.  The kernels cover what the training step runs: GPU, bf16
 (autocast), head size 64, L <= 128 tokens; every other case is torch's scaled_dot_product_attention on the same
-tensors.  Dropout bits: Philox4x32-10 keyed by the CUDA generator's seed and offset (reproducible under
-torch.manual_seed; not the same stream as torch's own dropout).  `GLR_FUSED_ATTN=0` switches the kernels off."""
+tensors.  Dropout bits: a counter-based hash of the score's position (two rounds of a 32-bit multiply-xorshift mixer,
+16 bits per score: csrc/glr_attn.hip) KEYED by the CUDA generator's (seed, offset) drawn the same way the sub-layer
+epilogues draw their Philox keys (fused_ln._philox_args) - reproducible under torch.manual_seed, not the same stream as
+torch's own dropout.  The epilogues use Philox4x32-10 itself; here it cost 40 quarter-rate integer multiplies per 8
+scores in a kernel that is VALU-bound, so the per-score draw is the cheaper mixer and only the KEY comes from Philox's
+counter.  `GLR_FUSED_ATTN=0` switches the kernels off."""
 
 import math
 import os

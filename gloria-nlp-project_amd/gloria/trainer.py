@@ -54,12 +54,15 @@ class Trainer:
         if self.sync_bn and self.dist is not None and self.dist.world_size > 1:
             model.gloria.img_encoder = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model.gloria.img_encoder,
                                                                                       self.dist.group)
-        if self.flat_optimizer:
-            self.cfg.set_path("train.optimizer.flat_bf16", True)
-            self.cfg.set_path("train.optimizer.flat_clip", self.clip)
-            # data-parallel ranks gather every bucket's gradients into a flat buffer (all-reduced slice by slice during
-            # backward); a single process reads the gradients where autograd leaves them (pointer table)
-            self.cfg.set_path("train.optimizer.flat_grads", bool(self.dist is not None and self.dist.active))
+        # how build_optimizer is to build the optimizer for THIS run, written explicitly in both cases: the cfg also
+        # travels inside checkpoints (hyper_parameters), and a stale `flat_bf16: True` from a bf16 run must not hand an
+        # fp32 / GLR_FLAT_OPTIMIZER=0 run bf16 parameters.
+        # data-parallel ranks gather every bucket's gradients into a flat buffer (all-reduced slice by slice during
+        # backward); a single process reads the gradients where autograd leaves them (pointer table)
+        self.cfg.set_path("train.optimizer.flat_bf16", bool(self.flat_optimizer))
+        self.cfg.set_path("train.optimizer.flat_clip", self.clip if self.flat_optimizer else None)
+        self.cfg.set_path("train.optimizer.flat_grads",
+                          bool(self.flat_optimizer and self.dist is not None and self.dist.active))
         opt = model.configure_optimizers()
         self.optimizer, self.scheduler = opt["optimizer"], opt["lr_scheduler"]
         self.params = [p for g in self.optimizer.param_groups for p in g["params"]]

@@ -289,8 +289,14 @@ def test_optimizer_state_crosses_between_stock_and_flat_adam_by_parameter(tmp_pa
         tr2, m2 = make(not src_flat, 6)
         tr2.resume(m2, str(ck))
         got = moments(tr2, m2)
-        assert set(want) == set(got) and len(want) > 300
-        for n in want:
+        # stock Adam holds state only for parameters that have received a gradient, the flat optimizer for all of its
+        # parameters from the start (zeros): compare what both hold, and what only one holds must be all zeros
+        common = set(want) & set(got)
+        assert len(common) > 300, (sorted(set(want) ^ set(got))[:10], len(want), len(got))
+        for n in set(want) ^ set(got):
+            m = (want.get(n) or got.get(n))
+            assert float(m[0].abs().max()) == 0.0 and float(m[1].abs().max()) == 0.0, n
+        for n in common:
             np.testing.assert_allclose(got[n][0].numpy(), want[n][0].numpy(), rtol=0, atol=0, err_msg=n)
             np.testing.assert_allclose(got[n][1].numpy(), want[n][1].numpy(), rtol=0, atol=0, err_msg=n)
         if not src_flat:

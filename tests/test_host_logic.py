@@ -229,3 +229,30 @@ def test_planner_caps_sentences_per_tile_when_that_saves_work_items():
     nsub = p.tile_nsub.numpy()
     first_ordinary = int(np.argmax(nsub == 0)) if (nsub == 0).any() else len(nsub)
     assert (nsub[first_ordinary:] == 0).all()                            # ordinary tiles are contiguous at the end
+
+
+def test_chexpert_pretrain_config_builds_and_steps_on_cpu():
+    """BASELINE.json configs[0]: chexpert_pretrain_config.yaml semantics (no no_attn_vec, weights 1 / 1, temps 4 / 5 / 10,
+    sentence-level captions) instantiated through the builder; one CPU forward of the encoders + the oracle loss (the
+    reference-structured CPU path: plumbing only, no GPU)."""
+    import torch
+    from gloria import builder
+    from gloria.config import pretrain_config
+    from gloria.datasets.synthetic import make_batch
+    from oracle import gloria_oracle as orc
+    cfg = pretrain_config("chexpert", batch_size=4)
+    assert cfg.data.dataset == "chexpert" and cfg.data.text.full_report is False
+    g = cfg.model.gloria
+    assert (g.local_loss_weight, g.global_loss_weight, g.temp1, g.temp2, g.temp3) == (1.0, 1.0, 4.0, 5.0, 10.0)
+    assert not g.no_attn_vec and g.no_attn_loss_weight is None and g.segmentation_loss_weight is None
+    cfg.set_path("model.text.bert_config", dict(num_hidden_layers=1, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0))
+    torch.manual_seed(0)
+    model = builder.build_lightning_model(cfg, builder.build_data_module(cfg))
+    assert model.gloria.no_attn_vec is None
+    batch = make_batch(4, seed=2)
+    il, ig, tl, tg, sents = model.gloria(batch)
+    assert il.shape == (4, 768, 19, 19) and ig.shape == (4, 768) and tl.shape == (4, 768, 97) and tg.shape == (4, 768)
+    loss, maps = orc.calc_loss(il, ig, tl, tg, sents, temp1=g.temp1, temp2=g.temp2, temp3=g.temp3)
+    assert torch.isfinite(loss) and len(maps) == 4
+    opt = model.configure_optimizers()["optimizer"]
+    assert opt.param_groups[0]["betas"] == (0.5, 0.999) and abs(opt.param_groups[0]["lr"] - 5e-5) < 1e-12
