@@ -29,6 +29,17 @@
 
 #include "glr_k1.h"
 
+// timing-only diagnostic build (make ablate): a phase is skipped when its bit is set in GLR_K1_DBG - results are garbage,
+// only the run time matters (tools/ablate_k1_t1.py); never compiled into libglr.so
+//   1 score stream (P1)   2 statistics passes   4 P2   8 Gram stream (P3)   16 P4
+//   32 P1 / P3 without their B loads (the registers keep the prologue's chunks): what the L2 -> register path costs
+//   64 P1 without its A staging
+#ifdef GLR_ABLATE
+#define GLR_SKIP(bit) (p.dbg & (bit))
+#else
+#define GLR_SKIP(bit) false
+#endif
+
 namespace {
 
 constexpr int NT1 = 256;
@@ -196,12 +207,16 @@ __global__ void __launch_bounds__(NT1, 2) k_local_attn_t1(LaParams p) {
         }
       if (LOADB) {
         const unsigned char* bn = bp + (size_t)(c + 2) * bstep;
+        if (!GLR_SKIP(32)) {
 #pragma unroll
         for (int j = 0; j < 3; ++j)
 #pragma unroll
           for (int kk = 0; kk < 2; ++kk) bq0[j][kk] = ldg(bn + j * 8192 + kk * 1024);
+        }
+        if (!GLR_SKIP(64)) {
         rst[((B0 + 2) & 3) * 256] = w0;
         if (STAGE) w0 = ldg16(ap + (size_t)(c + 6) * TW * CB);
+        }
       }
 #pragma unroll
       for (int wb = 0; wb < 2; ++wb)
@@ -216,18 +231,23 @@ __global__ void __launch_bounds__(NT1, 2) k_local_attn_t1(LaParams p) {
         }
       if (LOADB) {
         const unsigned char* bn = bp + (size_t)(c + 3) * bstep;
+        if (!GLR_SKIP(32)) {
 #pragma unroll
         for (int j = 0; j < 3; ++j)
 #pragma unroll
           for (int kk = 0; kk < 2; ++kk) bq1[j][kk] = ldg(bn + j * 8192 + kk * 1024);
+        }
+        if (!GLR_SKIP(64)) {
         rst[((B0 + 3) & 3) * 256] = w1;
         if (STAGE) w1 = ldg16(ap + (size_t)(c + 7) * TW * CB);
+        }
       }
       __syncthreads();
     };
     using T = std::true_type; using F = std::false_type;
     using I0 = std::integral_constant<int, 0>; using I2 = std::integral_constant<int, 2>;
     int c = 0;
+    if (!GLR_SKIP(1)) {
     for (; c + 12 <= nch1; c += 4) {                 // nch1 % 4 == 0 (host check): ends at c = nch1 - 8
       half_step(c, I0{}, ast2, ast3, T{}, T{});
       half_step(c + 2, I2{}, ast0, ast1, T{}, T{});
@@ -236,6 +256,7 @@ __global__ void __launch_bounds__(NT1, 2) k_local_attn_t1(LaParams p) {
     half_step(c + 2, I2{}, ast0, ast1, T{}, F{});
     half_step(c + 4, I0{}, ast2, ast3, T{}, F{});
     half_step(c + 6, I2{}, ast0, ast1, F{}, F{});    // chunks nch1 - 2 / - 1: nothing left to fetch
+    }
   }
 
   // run boundaries of this tile (scalar: same for every lane of a half)
@@ -269,6 +290,7 @@ __global__ void __launch_bounds__(NT1, 2) k_local_attn_t1(LaParams p) {
         for (int j = 0; j < 3; ++j) { tm[s2 * SP + 128 * j] = -INFINITY; ts[s2 * SP + 128 * j] = 0.f; }
       }
     }
+    if (!GLR_SKIP(2)) {
     // ---- pass 1: run maxima
     {
       float rm[3] = {-INFINITY, -INFINITY, -INFINITY};
@@ -344,11 +366,12 @@ __global__ void __launch_bounds__(NT1, 2) k_local_attn_t1(LaParams p) {
         if (dst != nullptr) dst[128 * j] = l2 * LN2;
       }
     }
+    }
     // the run-sum tables share their bytes with the image: every wave must be done reading them
     __syncthreads();
 
     // ---- P2: a1, e2 from the scores in registers; LDS image; per-word dot~
-    {
+    if (!GLR_SKIP(4)) {
       float lc[3] = {0.f, 0.f, 0.f};
       unsigned* a1out = p.a1buf == nullptr ? nullptr
                         : p.a1buf + (((size_t)b * p.a1_items + p.a1_base + item) * 8 + (t + 2 * wg)) * (2 * 3 * 8 * 64) + lane;
@@ -446,7 +469,7 @@ __global__ void __launch_bounds__(NT1, 2) k_local_attn_t1(LaParams p) {
           O::mma(fa[0][kk], bq0[j][kk], acc0[j]);
           O::mma(fa[1][kk], bq0[j][kk], acc1[j]);
         }
-      if (LOADB) {
+      if (LOADB && !GLR_SKIP(32)) {
         const unsigned char* bn = gp + (size_t)(c + 2) * bstep;
 #pragma unroll
         for (int j = 0; j < 3; ++j)
@@ -464,7 +487,7 @@ __global__ void __launch_bounds__(NT1, 2) k_local_attn_t1(LaParams p) {
           O::mma(fa[0][kk], bq1[j][kk], acc0[j]);
           O::mma(fa[1][kk], bq1[j][kk], acc1[j]);
         }
-      if (LOADB) {
+      if (LOADB && !GLR_SKIP(32)) {
         const unsigned char* bn = gp + (size_t)(c + 3) * bstep;
 #pragma unroll
         for (int j = 0; j < 3; ++j)
@@ -472,9 +495,11 @@ __global__ void __launch_bounds__(NT1, 2) k_local_attn_t1(LaParams p) {
           for (int kk = 0; kk < 2; ++kk) bq1[j][kk] = ldg(bn + j * 8192 + kk * 1024);
       }
     };
+    if (!GLR_SKIP(8)) {
     int c = 0;
     for (; c + 4 <= nch2; c += 2) gram_step(c, std::true_type{});
     gram_step(c, std::false_type{});              // the last two chunks: nothing left to fetch
+    }
   }
 
   // ================= P4: Z from the ones row, |c|^2, cosine, per-sentence aggregate, maps =================
@@ -487,7 +512,7 @@ __global__ void __launch_bounds__(NT1, 2) k_local_attn_t1(LaParams p) {
     }
   }
   __syncthreads();                              // dsum's readers of `red` are done before it is rewritten
-  {
+  if (!GLR_SKIP(16)) {
     const float ok2 = (rbase + 256 < p.S_eff) ? 1.f : 0.f;      // padded columns (incl. the Z column) live in block 2 only
     float* redt = red + rslot * TW + 4 * h;
 #pragma unroll
@@ -574,6 +599,9 @@ int glr_k1_launch_tiles(LaParams& p, int op_dtype, void* stream) {
   p.img_block = env_ib > 0 ? env_ib : 4;
   const int per_xcd = ((p.B_img + 7) / 8 + p.img_block - 1) / p.img_block * p.img_block;
   const int grid = per_xcd * 8 * p.n_items * 2;
+#ifdef GLR_ABLATE
+  { const char* e = getenv("GLR_K1_DBG"); p.dbg = e ? atoi(e) : 0; }
+#endif
   static GlrLdsAttr la;
   if (glr_ensure_lds(la, (const void*)k_local_attn_t1, LDS_T1) != GLR_OK) return GLR_ELAUNCH;
   hipLaunchKernelGGL(k_local_attn_t1, dim3(grid), dim3(NT1), LDS_T1, (hipStream_t)stream, p);

@@ -60,7 +60,7 @@ def _compare(a, b):
         assert abs(na - nb) <= 0.25 * max(na, nb) + 1e-6, k
     assert set(a[3]) == set(b[3]) and len(a[3]) >= 100
     for k in a[3]:                                             # image encoder: same stream, same kernels in both runs
-        np.testing.assert_allclose(a[3][k].numpy(), b[3][k].numpy(), rtol=2e-3, atol=1e-5, err_msg=k)
+        np.testing.assert_allclose(a[3][k].numpy(), b[3][k].numpy(), rtol=2e-3, atol=1e-4, err_msg=k)
 
 
 def test_two_stream_encoders_equal_single_stream():

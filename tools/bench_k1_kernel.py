@@ -1,0 +1,35 @@
+"""K1 forward, kernel-only and op-level time at the bench shape (HIP events around the launches: gloria_loss.PROFILE).
+    python tools/bench_k1_kernel.py [B] [iters] [lens: words|max]
+Environment knobs are read by libglr once per process (GLR_K1_T1, GLR_K1_IMG_BLOCK): one process per setting."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "gloria-nlp-project_amd"))
+import numpy as np, torch
+from gloria.loss import gloria_loss as gl
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+iters = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+mode = sys.argv[3] if len(sys.argv) > 3 else "words"
+dev = "cuda:0"
+g = torch.Generator(dev).manual_seed(1234)
+img = (torch.randn(B, 768, 19, 19, device=dev, generator=g) * 0.5).bfloat16().contiguous(memory_format=torch.channels_last)
+words = (torch.randn(B, 768, 97, device=dev, generator=g) * 0.5).bfloat16()
+na = (torch.randn(768, device=dev, generator=g) * 0.5).bfloat16() if os.environ.get("NO_ATTN", "0") == "1" else None
+if mode == "max":
+    lens = [96] * B
+else:   # the bench's captions: word counts U{4..39} + [CLS]
+    lens = sorted((int(x) + 1 for x in np.random.default_rng(1234).integers(4, 40, size=B)), reverse=True)
+for _ in range(3):
+    gl.local_similarity(img, words, lens, want_attn=False, no_attn_vec=na)
+torch.cuda.synchronize()
+gl.PROFILE = {}
+for _ in range(iters):
+    gl.local_similarity(img, words, lens, want_attn=False, no_attn_vec=na)
+torch.cuda.synchronize()
+prof, gl.PROFILE = gl.PROFILE, None
+ms = lambda k: sorted(a.elapsed_time(b) for a, b in prof[k])
+k, o = ms("k1_fwd"), ms("k1_fwd_op")
+fl = prof["k1_flops"][0]
+print(f"B={B} {mode} sum(cap_lens)={sum(lens)} T1={os.environ.get('GLR_K1_T1', '1')} IB={os.environ.get('GLR_K1_IMG_BLOCK', '-')}: "
+      f"kernel median {k[len(k)//2]:.3f} ms (min {k[0]:.3f}) = {fl / k[len(k)//2] / 1e9:.0f} TFLOP/s = {fl / k[len(k)//2] / 1e9 / 2500:.3f} of peak; "
+      f"op median {o[len(o)//2]:.3f} ms = {fl / o[len(o)//2] / 1e9 / 2500:.3f}", flush=True)
