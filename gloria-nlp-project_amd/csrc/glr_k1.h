@@ -62,8 +62,8 @@ struct LaParams {
 // one tile's 64 word slots) x K bytes is stored as K / 64 chunks of R * 64 bytes; inside a chunk the 16-byte pieces
 // are FRAGMENT-MAJOR: [32-row block][slot = 16-byte piece of the 64-byte row][row in block].  One MFMA fragment load of
 // a wave (32 rows x the two pieces of a k-step) is then 1 KiB of contiguous memory, so an operand that only ONE wave
-// needs goes straight from global memory to registers in full lines; LDS-DMA pieces (16 rows x 4 slots) read four
-// 256-byte runs.
+// needs goes straight from global memory to registers in full lines; the LDS rings of the DMA streams hold a chunk in
+// this very order (a piece = a linear 1-KiB copy, fragment reads conflict-free without a swizzle).
 __host__ __device__ __forceinline__ constexpr int glr_ktile_off(int row, int slot) {
   return (row >> 5) * 2048 + slot * 512 + (row & 31) * 16;
 }

@@ -152,7 +152,7 @@ __device__ __forceinline__ void stream_gemm_n(f32x16 (&acc)[3], f32x16 (&acc2)[3
                                               const unsigned char* bsrc, size_t bpitch, int brows, int nchunk,
                                               const unsigned char* aimg, int aimg_pitch, int wave, int lane, int wm,
                                               int wg, int nrb, int tw) {
-  constexpr int PPR = CHB / 16, RPB = 256 / CHB, KSTEPS = CHB / 32, RPI = 64 / PPR;
+  constexpr int KSTEPS = CHB / 32, RPI = 16;          // a 1-KiB DMA piece = half a 32-row block (2 of its 4 slots)
   constexpr int PDD = NB - 1;                          // chunks issued ahead; buffer (c+PDD) % NB == (c-1) % NB
   constexpr bool STAG = GLR_STAGGER && PDD == 3;
   static_assert(PDD == 1 || PDD == 3, "wait immediates are written for 2- and 4-deep rings");
@@ -165,17 +165,18 @@ __device__ __forceinline__ void stream_gemm_n(f32x16 (&acc)[3], f32x16 (&acc2)[3
   const bool active = wm * 32 < tw;                    // fp32 tiles hold 32 words: odd waves only move data
   const int winstr = (arows + brows) / RPI;            // 1-KiB DMA pieces per chunk
   const unsigned ring_lds = lds_addr(ring);
-  const int prow = lane / PPR, pslot = lane % PPR;
-  int koff[KSTEPS];                                    // byte offset of k-step kk inside a swizzled row
+  // The ring buffer holds a chunk exactly as HBM does (glr_k1.h, glr_ktile_off): [32-row block][16-byte slot][row].
+  // A DMA piece is then a LINEAR 1-KiB copy, and the fragment a lane reads for k-step kk of a block - slot kk * 2 + h,
+  // row l31 - sits at consecutive 16-byte addresses along the lanes of a half: conflict-free without any swizzle.
+  int koff[KSTEPS];                                    // byte offset of k-step kk inside a 32-row block
 #pragma unroll
-  for (int kk = 0; kk < KSTEPS; ++kk) koff[kk] = ((kk * 2 + h) ^ ((l31 / RPB) & (PPR - 1))) * 16;
-  // every row this lane reads is (multiple of 16) + l31, so its swizzle term depends on l31 only.
+  for (int kk = 0; kk < KSTEPS; ++kk) koff[kk] = (kk * 2 + h) * 512 + l31 * 16;
   // Region blocks this wave does not own (small S_pad only) are clamped to a valid row block and their
   // accumulators are simply never read: NO branches inside the k loop (a guarded load+MFMA pair compiles
   // to load / wait / MFMA in its own basic block and serialises on the LDS latency)
   int bofs[3];
 #pragma unroll
-  for (int j = 0; j < 3; ++j) bofs[j] = (arows + min(wg + 4 * j, nrb - 1) * 32 + l31) * CHB;
+  for (int j = 0; j < 3; ++j) bofs[j] = (arows / 32 + min(wg + 4 * j, nrb - 1)) * 2048;
 
   // every wave issues exactly NPWC pieces per chunk (piece indices past the end are clamped to the
   // last piece: two waves then write the same bytes to the same LDS slot, which is harmless)
@@ -185,17 +186,12 @@ __device__ __forceinline__ void stream_gemm_n(f32x16 (&acc)[3], f32x16 (&acc2)[3
 #pragma unroll
   for (int i = 0; i < NPWC; ++i) {
     const int k = min(wave + 8 * i, winstr - 1);
-    const int row = k * RPI + prow;
-    const int g = pslot ^ ((row / RPB) & (PPR - 1));
-    // Operands are K-TILED in HBM (glr_k1.h, glr_ktile_off): a block of R rows is stored [K chunk][32-row block]
-    // [16-byte slot][row], so every DMA piece (16 rows x 4 slots) reads four 256-byte runs of whole lines (row-major
-    // operands gave 64-byte fragments of 16 different rows per piece: half of every 128-byte line fetched twice,
-    // 27 B/clk/CU instead of ~48).
-    // A row r of the ring = populated row (r % tw) of tile (r / tw); a tile block holds TW rows per chunk.
-    const bool is_a = row < arows;
-    const int tl = row / tw, rr = row - tl * tw;
-    const size_t off = is_a ? (size_t)tl * TW * apitch + (size_t)glr_ktile_off(rr, g) : (size_t)glr_ktile_off(row - arows, g);
-    psrc[i] = (is_a ? asrc : bsrc) + off;
+    const int row0 = (k >> 1) * 32;                    // first ring row of the piece's block; its half: k & 1
+    // A rows of the ring = populated rows [0, tw) of tile (row / tw); a tile block holds TW rows per chunk in HBM.
+    const bool is_a = row0 < arows;
+    const int tl = row0 / tw, rr0 = row0 - tl * tw;
+    const size_t off = is_a ? (size_t)tl * TW * apitch + (size_t)(rr0 / 32) * 2048 : (size_t)((row0 - arows) / 32) * 2048;
+    psrc[i] = (is_a ? asrc : bsrc) + off + (k & 1) * 1024 + lane * 16;
     pstep[i] = (is_a ? TW : brows) * CHB;                    // bytes from one K chunk to the next
     pdst[i] = ring_lds + k * 1024;
   }
@@ -208,7 +204,7 @@ __device__ __forceinline__ void stream_gemm_n(f32x16 (&acc)[3], f32x16 (&acc2)[3
     const unsigned char* rb = ring + (c % NB) * buf_bytes;
     if (active) {
       const unsigned char* aa0 = A_RES ? (aimg + (arow0 + l31) * aimg_pitch + c * CHB + h * 16)
-                                       : (rb + (arow0 + l31) * CHB);
+                                       : (rb + (arow0 / 32) * 2048);
       typename O::frag fa[KSTEPS], fa2[KSTEPS], fb[KSTEPS][3];
 #pragma unroll
       for (int kk = 0; kk < KSTEPS; ++kk) {

@@ -85,23 +85,42 @@ __device__ __forceinline__ frag ldg(const unsigned char* p) { return __builtin_b
 __global__ void __launch_bounds__(NT1, 2) k_local_attn_t1(LaParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
+  // Everything per-lane derives from `tid`, which is laundered at the top of every unit of the persistent walk: the
+  // dozens of per-lane addresses below are otherwise loop invariants that hipcc hoists in front of the loop and keeps
+  // live through every phase (200+ bytes of scratch per lane).
+  int tid = threadIdx.x;
+  int lane = tid & 63;
   const int wg = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave = region group
-  const int l31 = lane & 31, h = lane >> 5;
+  int l31 = lane & 31, h = lane >> 5;
 
-  // Block -> (image, tile).  Blocks with equal blockIdx % 8 share an XCD (speed only).  Per XCD the blocks walk groups
-  // of `img_block` images x all tiles, images innermost: the XCD's resident workgroups (64) then share img_block
-  // images (vt + gram: 885 KB each) and a few word tiles (98 KB each) in the 4 MiB L2.
-  const int xcd = blockIdx.x & 7, qq = blockIdx.x >> 3;
+  // PERSISTENT workgroups: the grid is two workgroups per CU; workgroup (xcd = blockIdx % 8, slot = blockIdx / 8) walks
+  // the units q = slot, slot + nslot, ... of "its" XCD (blocks with equal blockIdx % 8 share an XCD: speed only, never
+  // correctness).  Per XCD the units run over groups of `img_block` images x all tiles, images innermost: the XCD's 64
+  // resident workgroups then share img_block images (vt + gram: 885 KB each) and a few word tiles (98 KB each) in the
+  // 4 MiB L2.  All units cost the same (one full tile x one image), so the static walk is balanced; what persistence
+  // buys is that a unit's set-up words and first stream chunks are already in flight when the previous unit ends
+  // (`prefetch` below): no workgroup launch + dependent round trips (~4 us, ablation) in front of every unit.
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslot = gridDim.x >> 3;
   const int ib = p.img_block;
   const int n_units = 2 * p.n_items;
-  const int grp = qq / (ib * n_units), rem = qq - grp * (ib * n_units);
-  const int b = (grp * ib + rem % ib) * 8 + xcd;
-  if (b >= p.B_img) return;
-  const int unit = rem / ib;
-  const int item = unit >> 1, t = unit & 1;
-  const int tile = p.item_tile[item] + t;
+  const int q_end = (((p.B_img + 7) / 8 + ib - 1) / ib * ib) * n_units;
+  auto decode = [&](int q, int& ub, int& uitem, int& ut) {
+    const int grp = q / (ib * n_units), rem = q - grp * (ib * n_units);
+    ub = (grp * ib + rem % ib) * 8 + xcd;
+    const int unit = rem / ib;
+    uitem = unit >> 1;
+    ut = unit & 1;
+    return ub < p.B_img;
+  };
+  auto next_valid = [&](int q) {
+    for (; q < q_end; q += nslot) {
+      int ub, ui, ut;
+      if (decode(q, ub, ui, ut)) break;
+    }
+    return q;
+  };
+  int q = next_valid(slot);
+  if (q >= q_end) return;
   const int D = p.D;
 
   unsigned char* ring = smem;
@@ -118,37 +137,62 @@ __global__ void __launch_bounds__(NT1, 2) k_local_attn_t1(LaParams p) {
   float* zsum = tnl + TW;
   float* dsum = zsum + TW;
   float* red = dsum + TW;                                           // [8][TW]
+  int* dsc = misc + 16;
 
   const size_t rowbytes1 = (size_t)D * ESZ, rowbytes2 = (size_t)SP * ESZ;
-  const unsigned char* vt_b = p.vt + (size_t)b * SP * rowbytes1;
-  const unsigned char* gram_b = p.gram + (size_t)b * SP * rowbytes2;
-  const unsigned char* tp_t = p.tp + (size_t)tile * TW * rowbytes1;
   const int nch1 = (int)(rowbytes1 / CB), nch2 = (int)(rowbytes2 / CB);
-
-  // everything about the tile comes from the ONE 256-byte descriptor of its pair; its loads go out first so that the
-  // set-up below waits for them only, not for the stream's first chunks issued right behind them
-  int* dsc = misc + 16;
-  int dsc_v = 0;
-  float tn_v = 0.f;
-  if (tid < 64) {
-    dsc_v = p.pair_desc[(size_t)item * 64 + tid];
-    tn_v = p.tnorm[(size_t)tile * TW + tid];
-  }
-  // ---- the stream's first loads go out before anything else: B chunks 0 / 1 (registers), A chunks 0..3 (staging)
-  // lane's byte offset inside a 32-row fragment block: slot (kk * 2 + h), row l31
-  const int foff = h * 512 + l31 * 16;
-  const unsigned char* bp = vt_b + (size_t)wg * 2048 + foff;        // + c * SP * CB + j * 8192 + kk * 1024
+  int foff = h * 512 + l31 * 16;              // lane's byte offset inside a 32-row fragment block: slot (kk * 2 + h), row l31
   const size_t bstep = (size_t)SP * CB;
+
+  // What a unit needs first, ALWAYS loaded in this order (set-up words, then B chunk 0, then A chunks 0 / 1): the
+  // set-up of a unit waits for the two oldest loads only.  Called once in front of the walk and once per unit behind
+  // the Gram stream for the NEXT unit (the last unit re-loads itself: an unconditional sequence keeps hipcc's counted
+  // vmcnt waits exact across the loop's back edge).
+  int dsc_v;
+  float tn_v;
   frag bq0[3][2], bq1[3][2];
+  u32x4 ast0, ast1, ast2, ast3;
+  const unsigned char *bp_nx, *ap_nx;
+  auto prefetch = [&](int ub, int uitem, int utile) {
+    dsc_v = p.pair_desc[(size_t)uitem * 64 + (tid & 63)];
+    tn_v = p.tnorm[(size_t)utile * TW + (tid & 63)];
+    bp_nx = p.vt + (size_t)ub * SP * rowbytes1 + (size_t)wg * 2048 + foff;     // + c * SP * CB + j * 8192 + kk * 1024
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) bq0[j][kk] = ldg(bp_nx + j * 8192 + kk * 1024);
+    ap_nx = p.tp + (size_t)utile * TW * rowbytes1 + tid * 16;                   // + c * TW * CB: linear copy of the 4-KiB chunk
+    ast0 = ldg16(ap_nx);
+    ast1 = ldg16(ap_nx + TW * CB);
+  };
+  int b, item, t;
+  decode(q, b, item, t);
+  int tile = p.item_tile[item] + t;
+  prefetch(b, item, tile);
+
+  for (;;) {
+  asm volatile("" : "+v"(tid));
+  lane = tid & 63;
+  l31 = lane & 31;
+  h = lane >> 5;
+  foff = h * 512 + l31 * 16;
+  // the unit after this one (its tile index is a dependent scalar load: issued here, needed behind the Gram stream)
+  const int qn = next_valid(q + nslot);
+  const bool last = qn >= q_end;
+  int b_n = b, item_n = item, t_n = t;
+  if (!last) decode(qn, b_n, item_n, t_n);
+  int tile_nv = p.item_tile[item_n];     // a vector load behind the previous unit's stores; consumed (made scalar) behind P3
+  const unsigned char* bp = bp_nx;
+  const unsigned char* ap = ap_nx;
+  const unsigned char* gram_b = p.gram + (size_t)b * SP * rowbytes2;
+  // the rest of the stream's opening (B chunk 1, A chunks 2 / 3) goes out in front of the set-up: it has the set-up's
+  // barriers to arrive, and only chunk 0 had to cross the previous unit's P4 in registers
 #pragma unroll
   for (int j = 0; j < 3; ++j)
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      bq0[j][kk] = ldg(bp + j * 8192 + kk * 1024);
-      bq1[j][kk] = ldg(bp + bstep + j * 8192 + kk * 1024);
-    }
-  const unsigned char* ap = tp_t + tid * 16;                        // + c * TW * CB: linear copy of the 4-KiB chunk
-  u32x4 ast0 = ldg16(ap), ast1 = ldg16(ap + TW * CB), ast2 = ldg16(ap + 2 * TW * CB), ast3 = ldg16(ap + 3 * TW * CB);
+    for (int kk = 0; kk < 2; ++kk) bq1[j][kk] = ldg(bp + bstep + j * 8192 + kk * 1024);
+  ast2 = ldg16(ap + 2 * TW * CB);
+  ast3 = ldg16(ap + 3 * TW * CB);
 
   if (tid < 64) {
     dsc[tid] = dsc_v;
@@ -258,6 +302,14 @@ __global__ void __launch_bounds__(NT1, 2) k_local_attn_t1(LaParams p) {
     half_step(c + 6, I2{}, ast0, ast1, F{}, F{});    // chunks nch1 - 2 / - 1: nothing left to fetch
     }
   }
+
+  // the Gram stream's first chunk goes out NOW: it crosses the vector phases in registers (the phases leave room for
+  // 24 of them) instead of opening P3 with an exposed memory round trip
+  const unsigned char* gp = gram_b + (size_t)wg * 2048 + foff;
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) bq0[j][kk] = ldg(gp + j * 8192 + kk * 1024);     // chunk 1 follows behind P2 (registers)
 
   // run boundaries of this tile (scalar: same for every lane of a half)
   const int* fl = dsc + 32 + 8 * t;
@@ -430,18 +482,13 @@ __global__ void __launch_bounds__(NT1, 2) k_local_attn_t1(LaParams p) {
       }
     }
   }
-#undef GLR_SBIT
 
   // ================= P3: acc[w, r'] = E . G^T (K = S_pad); the A operand is the image, B rows go straight to registers ====
   {
-    const unsigned char* gp = gram_b + (size_t)wg * 2048 + foff;
 #pragma unroll
     for (int j = 0; j < 3; ++j)
 #pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        bq0[j][kk] = ldg(gp + j * 8192 + kk * 1024);
-        bq1[j][kk] = ldg(gp + bstep + j * 8192 + kk * 1024);
-      }
+      for (int kk = 0; kk < 2; ++kk) bq1[j][kk] = ldg(gp + bstep + j * 8192 + kk * 1024);
 #pragma unroll
     for (int j = 0; j < 3; ++j)
 #pragma unroll
@@ -501,6 +548,11 @@ __global__ void __launch_bounds__(NT1, 2) k_local_attn_t1(LaParams p) {
     gram_step(c, std::false_type{});              // the last two chunks: nothing left to fetch
     }
   }
+
+  // the next unit's set-up words and first chunks: in flight across P4, the epilogue and the next set-up
+  asm volatile("" : "+v"(tile_nv));             // (keeps hipcc from waiting for the index load at the top of the unit)
+  const int tile_n = __builtin_amdgcn_readfirstlane(tile_nv) + t_n;
+  prefetch(b_n, item_n, tile_n);
 
   // ================= P4: Z from the ones row, |c|^2, cosine, per-sentence aggregate, maps =================
   if (wg == 3 && l31 == 31) {                   // output column SP - 1 = sum_{r < S_eff} e2[w, r]
@@ -587,6 +639,11 @@ __global__ void __launch_bounds__(NT1, 2) k_local_attn_t1(LaParams p) {
       }
   }
 #undef GLR_SGK
+#undef GLR_SBIT
+  if (last) break;
+  q = qn; b = b_n; item = item_n; t = t_n; tile = tile_n;
+  __syncthreads();                              // every wave is done with this unit's image and tables
+  }
 }
 
 }  // namespace
@@ -597,8 +654,13 @@ int glr_k1_launch_tiles(LaParams& p, int op_dtype, void* stream) {
   if (p.D % 128 != 0 || p.D * ESZ / CB < 8) return GLR_EINVAL;      // the score stream walks four K chunks per iteration
   static const int env_ib = [] { const char* e = getenv("GLR_K1_IMG_BLOCK"); return e ? atoi(e) : 0; }();
   p.img_block = env_ib > 0 ? env_ib : 4;
+  // two resident workgroups per CU walk the units; never more workgroups than units per XCD
   const int per_xcd = ((p.B_img + 7) / 8 + p.img_block - 1) / p.img_block * p.img_block;
-  const int grid = per_xcd * 8 * p.n_items * 2;
+  const int units_per_xcd = per_xcd * p.n_items * 2;
+  int slots = glr_dev_cus() * 2 / 8;
+  if (slots > units_per_xcd) slots = units_per_xcd;
+  if (slots < 1) slots = 1;
+  const int grid = slots * 8;
 #ifdef GLR_ABLATE
   { const char* e = getenv("GLR_K1_DBG"); p.dbg = e ? atoi(e) : 0; }
 #endif

@@ -226,7 +226,7 @@ int glr_local_attn_bwd(const void* vt, const void* gram, const void* tp, const f
  * tile) is stored as [row_bytes / 64] chunks of rows * 64 bytes, and inside a chunk FRAGMENT-MAJOR:
  * [rows / 32][4 x 16-byte slot of the row's 64 bytes][32 rows][16 bytes].  The MFMA fragment one wave loads per k-step
  * (32 rows x 2 slots) is then 1 KiB of contiguous memory - operands only one wave needs go straight to registers in
- * whole lines - and an LDS-DMA piece of the K1 streams (16 rows x 4 slots) reads four 256-byte runs.
+ * whole lines - and an LDS-DMA piece of the K1 streams (half a block) is a linear 1-KiB copy.
  *   src   row-major [n_blocks * rows][row_bytes]     dst  same size, tiled     row_bytes % 64 == 0, rows % 32 == 0
  */
 int glr_tile_k(const void* src, void* dst, int rows, long long n_blocks, int row_bytes, void* stream);
