@@ -85,42 +85,23 @@ __device__ __forceinline__ frag ldg(const unsigned char* p) { return __builtin_b
 __global__ void __launch_bounds__(NT1, 2) k_local_attn_t1(LaParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
-  // Everything per-lane derives from `tid`, which is laundered at the top of every unit of the persistent walk: the
-  // dozens of per-lane addresses below are otherwise loop invariants that hipcc hoists in front of the loop and keeps
-  // live through every phase (200+ bytes of scratch per lane).
-  int tid = threadIdx.x;
-  int lane = tid & 63;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
   const int wg = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave = region group
-  int l31 = lane & 31, h = lane >> 5;
+  const int l31 = lane & 31, h = lane >> 5;
 
-  // PERSISTENT workgroups: the grid is two workgroups per CU; workgroup (xcd = blockIdx % 8, slot = blockIdx / 8) walks
-  // the units q = slot, slot + nslot, ... of "its" XCD (blocks with equal blockIdx % 8 share an XCD: speed only, never
-  // correctness).  Per XCD the units run over groups of `img_block` images x all tiles, images innermost: the XCD's 64
-  // resident workgroups then share img_block images (vt + gram: 885 KB each) and a few word tiles (98 KB each) in the
-  // 4 MiB L2.  All units cost the same (one full tile x one image), so the static walk is balanced; what persistence
-  // buys is that a unit's set-up words and first stream chunks are already in flight when the previous unit ends
-  // (`prefetch` below): no workgroup launch + dependent round trips (~4 us, ablation) in front of every unit.
-  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslot = gridDim.x >> 3;
+  // Block -> (image, tile).  Blocks with equal blockIdx % 8 share an XCD (speed only).  Per XCD the blocks walk groups
+  // of `img_block` images x all tiles, images innermost: the XCD's resident workgroups (64) then share img_block
+  // images (vt + gram: 885 KB each) and a few word tiles (98 KB each) in the 4 MiB L2.
+  const int xcd = blockIdx.x & 7, qq = blockIdx.x >> 3;
   const int ib = p.img_block;
   const int n_units = 2 * p.n_items;
-  const int q_end = (((p.B_img + 7) / 8 + ib - 1) / ib * ib) * n_units;
-  auto decode = [&](int q, int& ub, int& uitem, int& ut) {
-    const int grp = q / (ib * n_units), rem = q - grp * (ib * n_units);
-    ub = (grp * ib + rem % ib) * 8 + xcd;
-    const int unit = rem / ib;
-    uitem = unit >> 1;
-    ut = unit & 1;
-    return ub < p.B_img;
-  };
-  auto next_valid = [&](int q) {
-    for (; q < q_end; q += nslot) {
-      int ub, ui, ut;
-      if (decode(q, ub, ui, ut)) break;
-    }
-    return q;
-  };
-  int q = next_valid(slot);
-  if (q >= q_end) return;
+  const int grp = qq / (ib * n_units), rem = qq - grp * (ib * n_units);
+  const int b = (grp * ib + rem % ib) * 8 + xcd;
+  if (b >= p.B_img) return;
+  const int unit = rem / ib;
+  const int item = unit >> 1, t = unit & 1;
+  const int tile = p.item_tile[item] + t;
   const int D = p.D;
 
   unsigned char* ring = smem;
@@ -137,62 +118,39 @@ __global__ void __launch_bounds__(NT1, 2) k_local_attn_t1(LaParams p) {
   float* zsum = tnl + TW;
   float* dsum = zsum + TW;
   float* red = dsum + TW;                                           // [8][TW]
-  int* dsc = misc + 16;
 
   const size_t rowbytes1 = (size_t)D * ESZ, rowbytes2 = (size_t)SP * ESZ;
-  const int nch1 = (int)(rowbytes1 / CB), nch2 = (int)(rowbytes2 / CB);
-  int foff = h * 512 + l31 * 16;              // lane's byte offset inside a 32-row fragment block: slot (kk * 2 + h), row l31
-  const size_t bstep = (size_t)SP * CB;
+  const unsigned char* vt_b = p.vt + (size_t)b * SP * rowbytes1;
+  const unsigned char* gram_b = p.gram + (size_t)b * SP * rowbytes2;
+  const unsigned char* tp_t = p.tp + (size_t)tile * TW * rowbytes1;
+  const int nch1 = (int)(rowbytes1 / CB);
 
-  // What a unit needs first, ALWAYS loaded in this order (set-up words, then B chunk 0, then A chunks 0 / 1): the
-  // set-up of a unit waits for the two oldest loads only.  Called once in front of the walk and once per unit behind
-  // the Gram stream for the NEXT unit (the last unit re-loads itself: an unconditional sequence keeps hipcc's counted
-  // vmcnt waits exact across the loop's back edge).
-  int dsc_v;
-  float tn_v;
-  frag bq0[3][2], bq1[3][2];
-  u32x4 ast0, ast1, ast2, ast3;
-  const unsigned char *bp_nx, *ap_nx;
-  auto prefetch = [&](int ub, int uitem, int utile) {
-    dsc_v = p.pair_desc[(size_t)uitem * 64 + (tid & 63)];
-    tn_v = p.tnorm[(size_t)utile * TW + (tid & 63)];
-    bp_nx = p.vt + (size_t)ub * SP * rowbytes1 + (size_t)wg * 2048 + foff;     // + c * SP * CB + j * 8192 + kk * 1024
+  // everything about the tile comes from the ONE 256-byte descriptor of its pair; its loads go out first so that the
+  // set-up below waits for them only, not for the stream's first chunks issued right behind them
+  int* dsc = misc + 16;
+  int dsc_v = 0;
+  float tn_v = 0.f;
+  if (tid < 64) {
+    dsc_v = p.pair_desc[(size_t)item * 64 + tid];
+    tn_v = p.tnorm[(size_t)tile * TW + tid];
+  }
+  // ---- the stream's first loads go out before anything else: B chunks 0 / 1 (registers), A chunks 0..3 (staging)
+  // lane's byte offset inside a 32-row fragment block: slot (kk * 2 + h), row l31
+  const int foff = h * 512 + l31 * 16;
+  const unsigned char* bp = vt_b + (size_t)wg * 2048 + foff;        // + c * SP * CB + j * 8192 + kk * 1024
+  const size_t bstep = (size_t)SP * CB;
+  // THREE chunks of B fragments in flight per wave (72 registers): with two, a workgroup that streams alone - its CU
+  // partner being in a vector phase - keeps 48 KB in flight, half of what the L2 -> register path needs at its ~2000-
+  // cycle loaded latency (measured: streams at 42 B/clk/CU with both workgroups streaming, ~24 with one).
+  frag bq[3][3][2];                                                 // [set = chunk % 3][region block j][k-step]
+#pragma unroll
+  for (int u = 0; u < 3; ++u)
 #pragma unroll
     for (int j = 0; j < 3; ++j)
 #pragma unroll
-      for (int kk = 0; kk < 2; ++kk) bq0[j][kk] = ldg(bp_nx + j * 8192 + kk * 1024);
-    ap_nx = p.tp + (size_t)utile * TW * rowbytes1 + tid * 16;                   // + c * TW * CB: linear copy of the 4-KiB chunk
-    ast0 = ldg16(ap_nx);
-    ast1 = ldg16(ap_nx + TW * CB);
-  };
-  int b, item, t;
-  decode(q, b, item, t);
-  int tile = p.item_tile[item] + t;
-  prefetch(b, item, tile);
-
-  for (;;) {
-  asm volatile("" : "+v"(tid));
-  lane = tid & 63;
-  l31 = lane & 31;
-  h = lane >> 5;
-  foff = h * 512 + l31 * 16;
-  // the unit after this one (its tile index is a dependent scalar load: issued here, needed behind the Gram stream)
-  const int qn = next_valid(q + nslot);
-  const bool last = qn >= q_end;
-  int b_n = b, item_n = item, t_n = t;
-  if (!last) decode(qn, b_n, item_n, t_n);
-  int tile_nv = p.item_tile[item_n];     // a vector load behind the previous unit's stores; consumed (made scalar) behind P3
-  const unsigned char* bp = bp_nx;
-  const unsigned char* ap = ap_nx;
-  const unsigned char* gram_b = p.gram + (size_t)b * SP * rowbytes2;
-  // the rest of the stream's opening (B chunk 1, A chunks 2 / 3) goes out in front of the set-up: it has the set-up's
-  // barriers to arrive, and only chunk 0 had to cross the previous unit's P4 in registers
-#pragma unroll
-  for (int j = 0; j < 3; ++j)
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) bq1[j][kk] = ldg(bp + bstep + j * 8192 + kk * 1024);
-  ast2 = ldg16(ap + 2 * TW * CB);
-  ast3 = ldg16(ap + 3 * TW * CB);
+      for (int kk = 0; kk < 2; ++kk) bq[u][j][kk] = ldg(bp + u * bstep + j * 8192 + kk * 1024);
+  const unsigned char* ap = tp_t + tid * 16;                        // + c * TW * CB: linear copy of the 4-KiB chunk
+  u32x4 ast0 = ldg16(ap), ast1 = ldg16(ap + TW * CB), ast2 = ldg16(ap + 2 * TW * CB), ast3 = ldg16(ap + 3 * TW * CB);
 
   if (tid < 64) {
     dsc[tid] = dsc_v;
@@ -213,6 +171,7 @@ __global__ void __launch_bounds__(NT1, 2) k_local_attn_t1(LaParams p) {
     }
   }
 
+  using T = std::true_type; using F = std::false_type;
   // ================= P1: acc[w, r] = T . V^T (K = D) =================
   f32x16 acc0[3], acc1[3];
 #pragma unroll
@@ -227,89 +186,63 @@ __global__ void __launch_bounds__(NT1, 2) k_local_attn_t1(LaParams p) {
     ast1 = ldg16(ap + 5 * TW * CB);
     const unsigned char* ard = ring + foff;                         // + buf * 4096 + block * 2048 + kk * 1024
     __syncthreads();
-    // Half step = two K chunks: chunk c from registers bq0 + ring buffer B0, chunk c + 1 from bq1 + buffer B0 + 1;
-    // meanwhile the staged chunks c + 2 / c + 3 (registers w0 / w1, loaded three half steps ago) go into buffers
-    // B0 + 2 / B0 + 3, chunks c + 6 / c + 7 into those staging registers, and the B fragments of chunks c + 2 / c + 3
-    // into bq0 / bq1 right behind the MFMAs that read them.  One barrier per half step: it publishes the two ring
-    // writes and proves every wave has finished with the two buffers the NEXT half step overwrites.
-    // LOADB / STAGE are compile-time: a load under a run-time condition makes hipcc's waitcnt pass assume the shorter
-    // queue at the join, i.e. wait for (nearly) everything in flight at the top of every half step.
-    auto half_step = [&](int c, auto B0c, u32x4& w0, u32x4& w1, auto loadb, auto stage) {
-      constexpr int B0 = decltype(B0c)::value;
-      constexpr bool LOADB = decltype(loadb)::value, STAGE = decltype(stage)::value;
+    // One chunk (K = 32): A fragments from ring buffer CI % 4, B fragments from register set CI % 3; right behind the
+    // MFMAs that read them the set is refilled with chunk c + 3.  Behind every EVEN chunk the staged chunk c + 2
+    // (registers loaded three half steps ago) goes into ring buffer (CI + 2) % 4 and chunk c + 6 into those
+    // registers; behind every ODD chunk one barrier publishes the two ring writes and proves every wave has finished
+    // with the two buffers the next half step overwrites.  CI = chunk index inside a super-step of 12 chunks (the
+    // period of the 4-buffer ring, the 3 register sets and the two staging register pairs); LOADB / STAGE are
+    // compile-time: a load under a run-time condition makes hipcc's waitcnt pass assume the shorter queue at the join,
+    // i.e. wait for (nearly) everything in flight at the top of every chunk.
+    auto chunk = [&](int c, auto cic, u32x4& w, auto loadb, auto stage_wr, auto stage_ld) {
+      constexpr int CI = decltype(cic)::value, BUF = CI & 3, SET = CI % 3;
+      constexpr bool LOADB = decltype(loadb)::value, WR = decltype(stage_wr)::value, LD = decltype(stage_ld)::value;
       frag fa[2][2];
 #pragma unroll
       for (int wb = 0; wb < 2; ++wb)
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) fa[wb][kk] = O::ld(ard + B0 * 4096 + wb * 2048 + kk * 1024);
+        for (int kk = 0; kk < 2; ++kk) fa[wb][kk] = O::ld(ard + BUF * 4096 + wb * 2048 + kk * 1024);
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-          O::mma(fa[0][kk], bq0[j][kk], acc0[j]);
-          O::mma(fa[1][kk], bq0[j][kk], acc1[j]);
+          O::mma(fa[0][kk], bq[SET][j][kk], acc0[j]);
+          O::mma(fa[1][kk], bq[SET][j][kk], acc1[j]);
         }
-      if (LOADB) {
-        const unsigned char* bn = bp + (size_t)(c + 2) * bstep;
-        if (!GLR_SKIP(32)) {
-#pragma unroll
-        for (int j = 0; j < 3; ++j)
-#pragma unroll
-          for (int kk = 0; kk < 2; ++kk) bq0[j][kk] = ldg(bn + j * 8192 + kk * 1024);
-        }
-        if (!GLR_SKIP(64)) {
-        rst[((B0 + 2) & 3) * 256] = w0;
-        if (STAGE) w0 = ldg16(ap + (size_t)(c + 6) * TW * CB);
-        }
-      }
-#pragma unroll
-      for (int wb = 0; wb < 2; ++wb)
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) fa[wb][kk] = O::ld(ard + (B0 + 1) * 4096 + wb * 2048 + kk * 1024);
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-          O::mma(fa[0][kk], bq1[j][kk], acc0[j]);
-          O::mma(fa[1][kk], bq1[j][kk], acc1[j]);
-        }
-      if (LOADB) {
+      if (LOADB && !GLR_SKIP(32)) {
         const unsigned char* bn = bp + (size_t)(c + 3) * bstep;
-        if (!GLR_SKIP(32)) {
 #pragma unroll
         for (int j = 0; j < 3; ++j)
 #pragma unroll
-          for (int kk = 0; kk < 2; ++kk) bq1[j][kk] = ldg(bn + j * 8192 + kk * 1024);
-        }
-        if (!GLR_SKIP(64)) {
-        rst[((B0 + 3) & 3) * 256] = w1;
-        if (STAGE) w1 = ldg16(ap + (size_t)(c + 7) * TW * CB);
-        }
+          for (int kk = 0; kk < 2; ++kk) bq[SET][j][kk] = ldg(bn + j * 8192 + kk * 1024);
       }
-      __syncthreads();
+      if (WR && !GLR_SKIP(64)) {
+        rst[((BUF + 2) & 3) * 256] = w;
+        if (LD) w = ldg16(ap + (size_t)(c + 6) * TW * CB);
+      }
+      if (CI & 1) __syncthreads();
     };
-    using T = std::true_type; using F = std::false_type;
-    using I0 = std::integral_constant<int, 0>; using I2 = std::integral_constant<int, 2>;
+  #define GLR_CI(n) std::integral_constant<int, n>{}
+    // staging registers by chunk: even chunks of half steps 0, 2, 4 use ast2, odd ast3; half steps 1, 3, 5 ast0 / ast1
     int c = 0;
     if (!GLR_SKIP(1)) {
-    for (; c + 12 <= nch1; c += 4) {                 // nch1 % 4 == 0 (host check): ends at c = nch1 - 8
-      half_step(c, I0{}, ast2, ast3, T{}, T{});
-      half_step(c + 2, I2{}, ast0, ast1, T{}, T{});
+    for (; c + 12 < nch1; c += 12) {                 // nch1 % 12 == 0 (host check)
+      chunk(c + 0, GLR_CI(0), ast2, T{}, T{}, T{});   chunk(c + 1, GLR_CI(1), ast3, T{}, T{}, T{});
+      chunk(c + 2, GLR_CI(2), ast0, T{}, T{}, T{});   chunk(c + 3, GLR_CI(3), ast1, T{}, T{}, T{});
+      chunk(c + 4, GLR_CI(4), ast2, T{}, T{}, T{});   chunk(c + 5, GLR_CI(5), ast3, T{}, T{}, T{});
+      chunk(c + 6, GLR_CI(6), ast0, T{}, T{}, T{});   chunk(c + 7, GLR_CI(7), ast1, T{}, T{}, T{});
+      chunk(c + 8, GLR_CI(8), ast2, T{}, T{}, T{});   chunk(c + 9, GLR_CI(9), ast3, T{}, T{}, T{});
+      chunk(c + 10, GLR_CI(10), ast0, T{}, T{}, T{}); chunk(c + 11, GLR_CI(11), ast1, T{}, T{}, T{});
     }
-    half_step(c, I0{}, ast2, ast3, T{}, T{});        // chunks nch1 - 8 / - 7: the last staging loads (chunks nch1 - 2 / - 1)
-    half_step(c + 2, I2{}, ast0, ast1, T{}, F{});
-    half_step(c + 4, I0{}, ast2, ast3, T{}, F{});
-    half_step(c + 6, I2{}, ast0, ast1, F{}, F{});    // chunks nch1 - 2 / - 1: nothing left to fetch
+    // the last 12 chunks: B loads while chunk c + 3 exists, ring writes while chunk c + 2 does, staging loads while c + 6 does
+    chunk(c + 0, GLR_CI(0), ast2, T{}, T{}, T{});   chunk(c + 1, GLR_CI(1), ast3, T{}, T{}, T{});
+    chunk(c + 2, GLR_CI(2), ast0, T{}, T{}, T{});   chunk(c + 3, GLR_CI(3), ast1, T{}, T{}, T{});
+    chunk(c + 4, GLR_CI(4), ast2, T{}, T{}, T{});   chunk(c + 5, GLR_CI(5), ast3, T{}, T{}, T{});
+    chunk(c + 6, GLR_CI(6), ast0, T{}, T{}, F{});   chunk(c + 7, GLR_CI(7), ast1, T{}, T{}, F{});
+    chunk(c + 8, GLR_CI(8), ast2, T{}, T{}, F{});   chunk(c + 9, GLR_CI(9), ast3, F{}, T{}, F{});
+    chunk(c + 10, GLR_CI(10), ast0, F{}, F{}, F{}); chunk(c + 11, GLR_CI(11), ast1, F{}, F{}, F{});
     }
   }
-
-  // the Gram stream's first chunk goes out NOW: it crosses the vector phases in registers (the phases leave room for
-  // 24 of them) instead of opening P3 with an exposed memory round trip
-  const unsigned char* gp = gram_b + (size_t)wg * 2048 + foff;
-#pragma unroll
-  for (int j = 0; j < 3; ++j)
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) bq0[j][kk] = ldg(gp + j * 8192 + kk * 1024);     // chunk 1 follows behind P2 (registers)
 
   // run boundaries of this tile (scalar: same for every lane of a half)
   const int* fl = dsc + 32 + 8 * t;
@@ -482,13 +415,18 @@ __global__ void __launch_bounds__(NT1, 2) k_local_attn_t1(LaParams p) {
       }
     }
   }
+#undef GLR_SBIT
 
   // ================= P3: acc[w, r'] = E . G^T (K = S_pad); the A operand is the image, B rows go straight to registers ====
   {
+    // (the vector phases above leave no room to carry the first Gram chunk through them: 24 registers more spill)
+    const unsigned char* gp = gram_b + (size_t)wg * 2048 + foff;
 #pragma unroll
-    for (int j = 0; j < 3; ++j)
+    for (int u = 0; u < 3; ++u)
 #pragma unroll
-      for (int kk = 0; kk < 2; ++kk) bq1[j][kk] = ldg(gp + bstep + j * 8192 + kk * 1024);
+      for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) bq[u][j][kk] = ldg(gp + u * bstep + j * 8192 + kk * 1024);
 #pragma unroll
     for (int j = 0; j < 3; ++j)
 #pragma unroll
@@ -502,57 +440,37 @@ __global__ void __launch_bounds__(NT1, 2) k_local_attn_t1(LaParams p) {
       dsum[tid] = d;
     }
     const unsigned char* aimg = img0 + l31 * IMP + h * 16;          // + wb * 32 * IMP + c * 64 + kk * 32
-    auto gram_step = [&](int c, auto loadb) {
+    auto gchunk = [&](auto cic, auto loadb) {
+      constexpr int C = decltype(cic)::value, SET = C % 3;
       constexpr bool LOADB = decltype(loadb)::value;
       frag fa[2][2];
 #pragma unroll
       for (int wb = 0; wb < 2; ++wb)
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) fa[wb][kk] = O::ld(aimg + wb * 32 * IMP + c * CB + kk * 32);
+        for (int kk = 0; kk < 2; ++kk) fa[wb][kk] = O::ld(aimg + wb * 32 * IMP + C * CB + kk * 32);
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-          O::mma(fa[0][kk], bq0[j][kk], acc0[j]);
-          O::mma(fa[1][kk], bq0[j][kk], acc1[j]);
+          O::mma(fa[0][kk], bq[SET][j][kk], acc0[j]);
+          O::mma(fa[1][kk], bq[SET][j][kk], acc1[j]);
         }
       if (LOADB && !GLR_SKIP(32)) {
-        const unsigned char* bn = gp + (size_t)(c + 2) * bstep;
+        const unsigned char* bn = gp + (size_t)(C + 3) * bstep;
 #pragma unroll
         for (int j = 0; j < 3; ++j)
 #pragma unroll
-          for (int kk = 0; kk < 2; ++kk) bq0[j][kk] = ldg(bn + j * 8192 + kk * 1024);
-      }
-#pragma unroll
-      for (int wb = 0; wb < 2; ++wb)
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) fa[wb][kk] = O::ld(aimg + wb * 32 * IMP + (c + 1) * CB + kk * 32);
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-          O::mma(fa[0][kk], bq1[j][kk], acc0[j]);
-          O::mma(fa[1][kk], bq1[j][kk], acc1[j]);
-        }
-      if (LOADB && !GLR_SKIP(32)) {
-        const unsigned char* bn = gp + (size_t)(c + 3) * bstep;
-#pragma unroll
-        for (int j = 0; j < 3; ++j)
-#pragma unroll
-          for (int kk = 0; kk < 2; ++kk) bq1[j][kk] = ldg(bn + j * 8192 + kk * 1024);
+          for (int kk = 0; kk < 2; ++kk) bq[SET][j][kk] = ldg(bn + j * 8192 + kk * 1024);
       }
     };
+    static_assert(SP * ESZ / CB == 12, "the Gram stream is written out for 12 chunks");
     if (!GLR_SKIP(8)) {
-    int c = 0;
-    for (; c + 4 <= nch2; c += 2) gram_step(c, std::true_type{});
-    gram_step(c, std::false_type{});              // the last two chunks: nothing left to fetch
+      gchunk(GLR_CI(0), T{}); gchunk(GLR_CI(1), T{}); gchunk(GLR_CI(2), T{}); gchunk(GLR_CI(3), T{});
+      gchunk(GLR_CI(4), T{}); gchunk(GLR_CI(5), T{}); gchunk(GLR_CI(6), T{}); gchunk(GLR_CI(7), T{});
+      gchunk(GLR_CI(8), T{}); gchunk(GLR_CI(9), F{}); gchunk(GLR_CI(10), F{}); gchunk(GLR_CI(11), F{});
     }
+#undef GLR_CI
   }
-
-  // the next unit's set-up words and first chunks: in flight across P4, the epilogue and the next set-up
-  asm volatile("" : "+v"(tile_nv));             // (keeps hipcc from waiting for the index load at the top of the unit)
-  const int tile_n = __builtin_amdgcn_readfirstlane(tile_nv) + t_n;
-  prefetch(b_n, item_n, tile_n);
 
   // ================= P4: Z from the ones row, |c|^2, cosine, per-sentence aggregate, maps =================
   if (wg == 3 && l31 == 31) {                   // output column SP - 1 = sum_{r < S_eff} e2[w, r]
@@ -639,11 +557,6 @@ __global__ void __launch_bounds__(NT1, 2) k_local_attn_t1(LaParams p) {
       }
   }
 #undef GLR_SGK
-#undef GLR_SBIT
-  if (last) break;
-  q = qn; b = b_n; item = item_n; t = t_n; tile = tile_n;
-  __syncthreads();                              // every wave is done with this unit's image and tables
-  }
 }
 
 }  // namespace
@@ -651,16 +564,11 @@ __global__ void __launch_bounds__(NT1, 2) k_local_attn_t1(LaParams p) {
 int glr_k1_launch_tiles(LaParams& p, int op_dtype, void* stream) {
   if (op_dtype != GLR_BF16 || p.S_pad != SP) return GLR_EINVAL;
   if (p.pair_desc == nullptr || p.S_eff >= p.S_pad || p.n_items <= 0) return GLR_EINVAL;
-  if (p.D % 128 != 0 || p.D * ESZ / CB < 8) return GLR_EINVAL;      // the score stream walks four K chunks per iteration
+  if (p.D % 384 != 0) return GLR_EINVAL;      // the score stream walks super-steps of 12 K chunks (caller: pair kernel otherwise)
   static const int env_ib = [] { const char* e = getenv("GLR_K1_IMG_BLOCK"); return e ? atoi(e) : 0; }();
   p.img_block = env_ib > 0 ? env_ib : 4;
-  // two resident workgroups per CU walk the units; never more workgroups than units per XCD
   const int per_xcd = ((p.B_img + 7) / 8 + p.img_block - 1) / p.img_block * p.img_block;
-  const int units_per_xcd = per_xcd * p.n_items * 2;
-  int slots = glr_dev_cus() * 2 / 8;
-  if (slots > units_per_xcd) slots = units_per_xcd;
-  if (slots < 1) slots = 1;
-  const int grid = slots * 8;
+  const int grid = per_xcd * 8 * p.n_items * 2;
 #ifdef GLR_ABLATE
   { const char* e = getenv("GLR_K1_DBG"); p.dbg = e ? atoi(e) : 0; }
 #endif
