@@ -545,25 +545,28 @@ __global__ void __launch_bounds__(NT1, 2) k_local_attn_t1(LaParams p) {
       if (p.agg == GLR_AGG_MEAN) v /= (float)seg_n[sg];
       p.sim[(size_t)b * p.ld_sim + seg_sent[sg]] = p.temp3 * __logf(v);
     }
+    dsum[tid] = z > 0.f ? 1.f / z : 0.f;        // 1 / Z_w for the optional outputs below (dsum is dead by now)
   }
   const int dw0 = misc[1], dn = misc[2];
+  const float* zinv = dsum;
+  if (p.amean != nullptr || (p.attn != nullptr && dn > 0)) __syncthreads();      // (workgroup-uniform condition)
   if (p.attn != nullptr && dn > 0) {            // the diagonal sentence lies inside this tile
     const int sout = p.S_eff - p.strip;
     float* out = p.attn + p.attn_off[p.img_offset + b];
     for (int idx = tid; idx < dn * sout; idx += NT1) {
       const int w = dw0 + idx / sout, r = idx % sout + p.strip;
-      out[idx] = O::to_f32(img0 + w * IMP + r * ESZ) / zsum[w];
+      out[idx] = O::to_f32(img0 + w * IMP + r * ESZ) * zinv[w];
     }
   }
   if (p.amean != nullptr) {
     // word-mean attention row A[r] = mean_w a2[w, r] of every sentence of the tile (aux regularisers,
-    // gloria_loss.py:131-139), from the e2 image and the per-word Z
+    // gloria_loss.py:131-139), from the e2 image and the per-word 1 / Z
     for (int r = tid; r < SP; r += NT1)
       for (int s2 = 0; s2 < NS; ++s2) {
         const int w0 = seg_w0[s2], n = seg_n[s2];
         if (w0 < 0) continue;
         float a = 0.f;
-        for (int w = w0; w < w0 + n; ++w) a += O::to_f32(img0 + w * IMP + r * ESZ) / zsum[w];
+        for (int w = w0; w < w0 + n; ++w) a = __builtin_fmaf(O::to_f32(img0 + w * IMP + r * ESZ), zinv[w], a);
         p.amean[((size_t)b * p.n_sent + seg_sent[s2]) * SP + r] = r < p.S_eff ? a / (float)n : 0.f;
       }
   }

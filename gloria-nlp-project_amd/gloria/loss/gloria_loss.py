@@ -523,8 +523,8 @@ class AttnSupFn(torch.autograd.Function):
         cl = np.asarray(cap_lens, dtype=np.int64)
         off = np.zeros(len(cl) + 1, dtype=np.int64)
         np.cumsum(cl * ih * iw, out=off[1:])
-        off_d = torch.from_numpy(off[:-1].copy()).to(dev)
-        cl_d = torch.from_numpy(cl.astype(np.int32)).to(dev)
+        off_d = N.upload(off[:-1].copy(), dev)
+        cl_d = N.upload(cl.astype(np.int32), dev)
         lab = labels.detach().to(torch.uint8).contiguous()
         a = attn_flat.detach().float().contiguous()
         loss_b = torch.empty(count, dtype=torch.float32, device=dev)

@@ -19,6 +19,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+from .. import _native as N
 from .bert import BertConfig, BertModel
 
 PAD, UNK, CLS, SEP, MASK = 0, 100, 101, 102, 103
@@ -233,7 +234,7 @@ class BertEncoder(nn.Module):
                 B, L = host.shape
                 dst, starts, n_words = wordpiece_slots(host, self.vocab)
                 sents = SentenceBatch(host, dst, starts, n_words, self.vocab, L)
-                dst_d = torch.from_numpy(dst.astype(np.int32)).to(layers[0].device, non_blocking=True)
+                dst_d = N.upload(dst.astype(np.int32), layers[0].device)
                 fused = WordpieceSegSumFn.apply(dst_d, self.aggregate_method == "mean", *layers)
                 word_embeddings = fused[0].permute(0, 2, 1)        # [B, L, D] view; permuted back below
                 sent_embeddings = fused[1]

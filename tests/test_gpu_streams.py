@@ -55,9 +55,12 @@ def _compare(a, b):
     num = sum(float(((a[2][k] - b[2][k]) ** 2).sum()) for k in a[2])
     den = sum(float((a[2][k] ** 2).sum()) for k in a[2])
     assert den > 0 and (num / den) ** 0.5 < 3e-2               # relative Frobenius distance of ALL gradients
+    gnorm = den ** 0.5
     for k in a[2]:                                             # and no tensor is missing its side-stream share
         na, nb = float(a[2][k].norm()), float(b[2][k].norm())
-        assert abs(na - nb) <= 0.25 * max(na, nb) + 1e-6, k
+        # (the floor covers gradients that are zero in exact arithmetic - e.g. the key bias, to which softmax is blind -
+        # and therefore pure rounding noise in both runs)
+        assert abs(na - nb) <= 0.25 * max(na, nb) + 1e-3 * gnorm, k
     assert set(a[3]) == set(b[3]) and len(a[3]) >= 100
     for k in a[3]:                                             # image encoder: same stream, same kernels in both runs
         np.testing.assert_allclose(a[3][k].numpy(), b[3][k].numpy(), rtol=2e-3, atol=1e-4, err_msg=k)

@@ -28,7 +28,8 @@ FAMILIES = [
 
 def family(name):
     if "k_local_attn" in name:
-        return "K1 bwd (k_local_attn)" if re.search(r"k_local_attn<[^>]*true>", name) else "K1 fwd (k_local_attn)"
+        bwd = "_bwd" in name or re.search(r"k_local_attn<[^>]*, true,", name)
+        return "K1 bwd (k_local_attn)" if bwd else "K1 fwd (k_local_attn)"
     for fam, pat in FAMILIES[2:]:
         if re.search(pat, name):
             return fam
