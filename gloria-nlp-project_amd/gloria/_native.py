@@ -34,7 +34,6 @@ SYMBOLS = {
     "glr_pack_regions_tiled": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                        c_void_p]),
     "glr_tile_gram": (c_int, [c_void_p, c_void_p, c_int, ctypes.c_longlong, c_int, c_int, c_void_p]),
-    "glr_gram_tiled": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "glr_pack_words": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                c_int, c_int, c_int, c_void_p]),
     "glr_local_attn_fwd": (c_int, [c_void_p] * 10 + [c_int, c_void_p, c_int, c_int, c_void_p] + [c_int] * 5 + [c_float] * 3 + [c_int, c_float, c_void_p, c_int,

@@ -34,7 +34,6 @@ _COMPUTE_DTYPE = None          # None = follow the input dtype
 PROFILE = None
 _DEBUG_HOOK = None          # diagnostics only: called with the K1 backward outputs (tools)
 HANDOVER_A1 = os.environ.get("GLR_K1_A1", "1") != "0"     # forward -> backward hand-over of a1 (A/B switch)
-GRAM_KERNEL = os.environ.get("GLR_GRAM_KERNEL", "1") != "0"  # bf16: glr_gram_tiled instead of bmm + glr_tile_gram (A/B switch)
 
 
 class _Range:
@@ -124,15 +123,11 @@ def _pack_operands(img_features, words, no_attn_vec, cap_lens, o):
     vt_t = torch.empty_like(vt)
     N.check(L.glr_pack_regions_tiled(N.ptr(img), in_code, layout, N.ptr(na), N.ptr(vt), N.ptr(vt_t), B, D, S, code, st),
             "glr_pack_regions_tiled")
-    # G[b] = V V^T, K-tiled, with the ones row (a padded region) out of which the forward kernels read
-    # Z_w = sum_r e2[w, r] (include/glr.h); every kernel masks padded regions, so nothing else sees the row
-    if code == N.GLR_BF16 and GRAM_KERNEL:
-        gram_t = torch.empty(B, s_pad, s_pad, dtype=odt, device=dev)
-        N.check(L.glr_gram_tiled(N.ptr(vt_t), N.ptr(gram_t), B, D, s_pad, s_eff, st), "glr_gram_tiled")
-    else:               # fp32 parity mode: library batched GEMM + tiling pass
-        gram = torch.bmm(vt, vt.transpose(1, 2))
-        gram_t = torch.empty_like(gram)
-        N.check(L.glr_tile_gram(N.ptr(gram), N.ptr(gram_t), s_pad, B, s_eff, code, st), "glr_tile_gram")
+    gram = torch.bmm(vt, vt.transpose(1, 2))            # plain batched GEMM (hipBLASLt): G[b] = V^T V
+    gram_t = torch.empty_like(gram)
+    # tiling + the ones row (a padded region) out of which the forward pair kernel reads Z_w = sum_r e2[w, r]
+    # (include/glr.h, tile_rowflags); every kernel masks padded regions, so nothing else sees the row
+    N.check(L.glr_tile_gram(N.ptr(gram), N.ptr(gram_t), s_pad, B, s_eff, code, st), "glr_tile_gram")
     tp = torch.empty(plan.n_slots, D, dtype=odt, device=dev)
     tnorm = torch.empty(plan.n_slots, dtype=torch.float32, device=dev)
     N.check(L.glr_pack_words(N.ptr(words), in_code, N.ptr(plan.sent_slot0), N.ptr(plan.cap_lens), N.ptr(tp),

@@ -234,11 +234,6 @@ int glr_tile_k(const void* src, void* dst, int rows, long long n_blocks, int row
  * forward pair kernel expects when S_eff < S_pad (row S_pad - 1: ones in columns r < S_eff, zeros after; see
  * tile_rowflags of glr_local_attn_fwd) - the row-major gram stays untouched. */
 int glr_tile_gram(const void* gram, void* gram_t, int S_pad, long long B, int S_eff, int op_dtype, void* stream);
-/* glr_gram_tiled (bf16): G[b] = V_b V_b^T computed from the K-TILED vt_t [B, S_pad, D] (glr_pack_regions_tiled) on the
- * matrix cores and written directly as the K-tiled Gram operand gram_t [B, S_pad, S_pad], ones row included (as
- * glr_tile_gram writes it) - one kernel instead of a library batched GEMM plus a tiling pass.  Replaces the role of
- * context.transpose(1, 2) in the second bmm of attention_fn (gloria_loss.py:35, :59) for the Gram formulation. */
-int glr_gram_tiled(const void* vt_t, void* gram_t, int B, int D, int S_pad, int S_eff, void* stream);
 
 
 /* ------------------------------------------------------------------------------------------

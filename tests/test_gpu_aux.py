@@ -161,37 +161,3 @@ def test_attention_supervision_gradient_through_k1(dtype, no_attn):
                 np.testing.assert_allclose(a, b, rtol=2e-3, atol=1e-6)
             else:
                 assert np.linalg.norm(a - b) / np.linalg.norm(b) < 0.05
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("S,shift,B", [(361, 1, 5), (361, 0, 3), (197, 0, 2), (130, 1, 2)])
-def test_gram_kernel_equals_gemm_plus_tiling(S, shift, B):
-    """glr_gram_tiled (one MFMA kernel: Gram matrix straight into the K-tiled operand layout, ones row included) against
-    the path it replaces - library batched GEMM + glr_tile_gram - on the same packed regions: the ones row and the
-    zero padding bit for bit, the Gram values to bf16 rounding (both accumulate in fp32, in different orders)."""
-    from gloria import _native as N
-    L = N.lib()
-    dev = "cuda:0"
-    D = 768
-    g = torch.Generator(dev).manual_seed(5)
-    img = (torch.randn(B, S, D, device=dev, generator=g) * 0.5).bfloat16()          # channels-last features [B, S, D]
-    na = (torch.randn(D, device=dev, generator=g) * 0.5).bfloat16() if shift else None
-    s_eff = S + shift
-    s_pad = L.glr_region_pad(s_eff)
-    vt = torch.empty(B, s_pad, D, dtype=torch.bfloat16, device=dev)
-    vt_t = torch.empty_like(vt)
-    N.check(L.glr_pack_regions_tiled(N.ptr(img), N.GLR_BF16, 1, N.ptr(na), N.ptr(vt), N.ptr(vt_t), B, D, S, N.GLR_BF16,
-                                     N.stream()), "pack")
-    gram = torch.bmm(vt, vt.transpose(1, 2))
-    want = torch.empty_like(gram)
-    N.check(L.glr_tile_gram(N.ptr(gram), N.ptr(want), s_pad, B, s_eff, N.GLR_BF16, N.stream()), "tile_gram")
-    got = torch.full_like(gram, float("nan"))
-    N.check(L.glr_gram_tiled(N.ptr(vt_t), N.ptr(got), B, D, s_pad, s_eff, N.stream()), "gram_tiled")
-    torch.cuda.synchronize()
-    w, x = want.float().cpu().numpy(), got.float().cpu().numpy()
-    assert np.isfinite(x).all()
-    np.testing.assert_allclose(x, w, rtol=1.6e-2, atol=2e-2)               # bf16 ulp of fp32 sums in different orders
-    exact = (w == 0.0) | (w == 1.0)                                         # padding, and the ones row
-    assert exact.sum() > 0 and np.array_equal(x[exact], w[exact])
-    if s_eff < s_pad:
-        assert (w == 1.0).sum() >= B * s_eff
