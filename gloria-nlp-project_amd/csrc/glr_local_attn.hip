@@ -1842,7 +1842,7 @@ extern "C" int glr_local_attn_fwd(const void* vt, const void* gram, const void* 
     // the 8-wave pair kernel; the ordinary pairs (two whole tiles) run one 4-wave workgroup per tile, two per CU
     // (glr_local_attn_t1.hip).  GLR_K1_T1=0 sends every pair to the pair kernel (A/B switch of tools/ and tests).
     static const bool use_t1 = [] { const char* e = getenv("GLR_K1_T1"); return !(e && e[0] == '0'); }();
-    const int n_pw = (use_t1 && D % 384 == 0) ? n_long_pair : n_pair;
+    const int n_pw = (use_t1 && D % 128 == 0 && D >= 256) ? n_long_pair : n_pair;
     p.a1buf = (unsigned*)a1buf; p.a1_items = n_pair;
     if (n_pw > 0) {
       p.item_tile = pair_tile; p.n_items = n_pw; p.pair_desc = pair_desc; p.a1_base = 0;

@@ -150,12 +150,12 @@ __global__ void __launch_bounds__(NT1, 2) k_local_attn_t1(LaParams p) {
   const int foff = h * 512 + l31 * 16;
   const unsigned char* bp = vt_b + (size_t)wg * 2048 + foff;        // + c * SP * CB + j * 8192 + kk * 1024
   const size_t bstep = (size_t)SP * CB;
-  // THREE chunks of B fragments in flight per wave (72 registers): with two, a workgroup that streams alone - its CU
-  // partner being in a vector phase - keeps 48 KB in flight, half of what the L2 -> register path needs at its ~2000-
-  // cycle loaded latency (measured: streams at 42 B/clk/CU with both workgroups streaming, ~24 with one).
-  frag bq[3][3][2];                                                 // [set = chunk % 3][region block j][k-step]
+  // Two chunks of B fragments per wave (48 registers).  Deeper queues were measured SLOWER (three sets with exact
+  // counted waits: 1.93 ms against 1.70 ms, gpurun_out/r03f): what covers a wave's load latency here is the CU's second
+  // workgroup, not the depth of its own queue.
+  frag bq[2][3][2];                                                 // [set = chunk parity][region block j][k-step]
 #pragma unroll
-  for (int u = 0; u < 3; ++u)
+  for (int u = 0; u < 2; ++u)
 #pragma unroll
     for (int j = 0; j < 3; ++j)
 #pragma unroll
@@ -197,61 +197,58 @@ __global__ void __launch_bounds__(NT1, 2) k_local_attn_t1(LaParams p) {
     ast1 = ldg16(ap + 5 * TW * CB);
     const unsigned char* ard = ring + foff;                         // + buf * 4096 + block * 2048 + kk * 1024
     __syncthreads();
-    // One chunk (K = 32): A fragments from ring buffer CI % 4, B fragments from register set CI % 3; right behind the
-    // MFMAs that read them the set is refilled with chunk c + 3.  Behind every EVEN chunk the staged chunk c + 2
-    // (registers loaded three half steps ago) goes into ring buffer (CI + 2) % 4 and chunk c + 6 into those
-    // registers; behind every ODD chunk one barrier publishes the two ring writes and proves every wave has finished
-    // with the two buffers the next half step overwrites.  CI = chunk index inside a super-step of 12 chunks (the
-    // period of the 4-buffer ring, the 3 register sets and the two staging register pairs); LOADB / STAGE are
-    // compile-time: a load under a run-time condition makes hipcc's waitcnt pass assume the shorter queue at the join,
-    // i.e. wait for (nearly) everything in flight at the top of every chunk.
-    auto chunk = [&](int c, auto cic, u32x4& w, auto loadb, auto stage_wr, auto stage_ld) {
-      constexpr int CI = decltype(cic)::value, BUF = CI & 3, SET = CI % 3;
+    // Half step = two K chunks: the A fragments of BOTH chunks are read up front (ring buffers B0, B0 + 1: one exposed
+    // LDS round trip per half step instead of one per chunk), chunk c runs against register set 0, chunk c + 1 against
+    // set 1; right behind the MFMAs that read a set it is refilled (chunks c + 2 / c + 3), the staged chunks c + 2 /
+    // c + 3 (registers w0 / w1, loaded three half steps ago) go into ring buffers B0 + 2 / B0 + 3 and chunks c + 6 /
+    // c + 7 into those registers.  One barrier per half step publishes the two ring writes and proves every wave has
+    // finished with the two buffers the NEXT half step overwrites.  LOADB / WR / LD are compile-time: a load under a
+    // run-time condition that differs between the paths of a join makes hipcc's waitcnt pass assume the shorter queue.
+    auto half_step = [&](int c, auto B0c, u32x4& w0, u32x4& w1, auto loadb, auto stage_wr, auto stage_ld) {
+      constexpr int B0 = decltype(B0c)::value;
       constexpr bool LOADB = decltype(loadb)::value, WR = decltype(stage_wr)::value, LD = decltype(stage_ld)::value;
-      frag fa[2][2];
+      frag fa[2][2][2];                                             // [chunk of the half step][word block][k-step]
 #pragma unroll
-      for (int wb = 0; wb < 2; ++wb)
+      for (int u = 0; u < 2; ++u)
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) fa[wb][kk] = O::ld(ard + BUF * 4096 + wb * 2048 + kk * 1024);
+        for (int wb = 0; wb < 2; ++wb)
 #pragma unroll
-      for (int kk = 0; kk < 2; ++kk)
+          for (int kk = 0; kk < 2; ++kk) fa[u][wb][kk] = O::ld(ard + (B0 + u) * 4096 + wb * 2048 + kk * 1024);
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-          O::mma(fa[0][kk], bq[SET][j][kk], acc0[j]);
-          O::mma(fa[1][kk], bq[SET][j][kk], acc1[j]);
+      for (int u = 0; u < 2; ++u) {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+          for (int j = 0; j < 3; ++j) {
+            O::mma(fa[u][0][kk], bq[u][j][kk], acc0[j]);
+            O::mma(fa[u][1][kk], bq[u][j][kk], acc1[j]);
+          }
+        if (LOADB && !GLR_SKIP(32)) {
+          const unsigned char* bn = bp + (size_t)(c + 2 + u) * bstep;
+#pragma unroll
+          for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) bq[u][j][kk] = ldg(bn + j * 8192 + kk * 1024);
         }
-      if (LOADB && !GLR_SKIP(32)) {
-        const unsigned char* bn = bp + (size_t)(c + 3) * bstep;
-#pragma unroll
-        for (int j = 0; j < 3; ++j)
-#pragma unroll
-          for (int kk = 0; kk < 2; ++kk) bq[SET][j][kk] = ldg(bn + j * 8192 + kk * 1024);
+        if (WR && !GLR_SKIP(64)) {
+          u32x4& w = u == 0 ? w0 : w1;
+          rst[((B0 + 2 + u) & 3) * 256] = w;
+          if (LD) w = ldg16(ap + (size_t)(c + 6 + u) * TW * CB);
+        }
       }
-      if (WR && !GLR_SKIP(64)) {
-        rst[((BUF + 2) & 3) * 256] = w;
-        if (LD) w = ldg16(ap + (size_t)(c + 6) * TW * CB);
-      }
-      if (CI & 1) __syncthreads();
+      __syncthreads();
     };
-  #define GLR_CI(n) std::integral_constant<int, n>{}
-    // staging registers by chunk: even chunks of half steps 0, 2, 4 use ast2, odd ast3; half steps 1, 3, 5 ast0 / ast1
+    using I0 = std::integral_constant<int, 0>; using I2 = std::integral_constant<int, 2>;
     int c = 0;
     if (!GLR_SKIP(1)) {
-    for (; c + 12 < nch1; c += 12) {                 // nch1 % 12 == 0 (host check)
-      chunk(c + 0, GLR_CI(0), ast2, T{}, T{}, T{});   chunk(c + 1, GLR_CI(1), ast3, T{}, T{}, T{});
-      chunk(c + 2, GLR_CI(2), ast0, T{}, T{}, T{});   chunk(c + 3, GLR_CI(3), ast1, T{}, T{}, T{});
-      chunk(c + 4, GLR_CI(4), ast2, T{}, T{}, T{});   chunk(c + 5, GLR_CI(5), ast3, T{}, T{}, T{});
-      chunk(c + 6, GLR_CI(6), ast0, T{}, T{}, T{});   chunk(c + 7, GLR_CI(7), ast1, T{}, T{}, T{});
-      chunk(c + 8, GLR_CI(8), ast2, T{}, T{}, T{});   chunk(c + 9, GLR_CI(9), ast3, T{}, T{}, T{});
-      chunk(c + 10, GLR_CI(10), ast0, T{}, T{}, T{}); chunk(c + 11, GLR_CI(11), ast1, T{}, T{}, T{});
+    for (; c + 12 <= nch1; c += 4) {                 // nch1 % 4 == 0 (host check): ends at c = nch1 - 8
+      half_step(c, I0{}, ast2, ast3, T{}, T{}, T{});
+      half_step(c + 2, I2{}, ast0, ast1, T{}, T{}, T{});
     }
-    // the last 12 chunks: B loads while chunk c + 3 exists, ring writes while chunk c + 2 does, staging loads while c + 6 does
-    chunk(c + 0, GLR_CI(0), ast2, T{}, T{}, T{});   chunk(c + 1, GLR_CI(1), ast3, T{}, T{}, T{});
-    chunk(c + 2, GLR_CI(2), ast0, T{}, T{}, T{});   chunk(c + 3, GLR_CI(3), ast1, T{}, T{}, T{});
-    chunk(c + 4, GLR_CI(4), ast2, T{}, T{}, T{});   chunk(c + 5, GLR_CI(5), ast3, T{}, T{}, T{});
-    chunk(c + 6, GLR_CI(6), ast0, T{}, T{}, F{});   chunk(c + 7, GLR_CI(7), ast1, T{}, T{}, F{});
-    chunk(c + 8, GLR_CI(8), ast2, T{}, T{}, F{});   chunk(c + 9, GLR_CI(9), ast3, F{}, T{}, F{});
-    chunk(c + 10, GLR_CI(10), ast0, F{}, F{}, F{}); chunk(c + 11, GLR_CI(11), ast1, F{}, F{}, F{});
+    half_step(c, I0{}, ast2, ast3, T{}, T{}, T{});        // chunks nch1 - 8 / - 7: the last staging loads (chunks nch1 - 2 / - 1)
+    half_step(c + 2, I2{}, ast0, ast1, T{}, T{}, F{});
+    half_step(c + 4, I0{}, ast2, ast3, T{}, T{}, F{});
+    half_step(c + 6, I2{}, ast0, ast1, F{}, F{}, F{});    // chunks nch1 - 2 / - 1: nothing left to fetch
     }
   }
 
@@ -430,10 +427,9 @@ __global__ void __launch_bounds__(NT1, 2) k_local_attn_t1(LaParams p) {
 
   // ================= P3: acc[w, r'] = E . G^T (K = S_pad); the A operand is the image, B rows go straight to registers ====
   {
-    // (the vector phases above leave no room to carry the first Gram chunk through them: 24 registers more spill)
     const unsigned char* gp = gram_b + (size_t)wg * 2048 + foff;
 #pragma unroll
-    for (int u = 0; u < 3; ++u)
+    for (int u = 0; u < 2; ++u)
 #pragma unroll
       for (int j = 0; j < 3; ++j)
 #pragma unroll
@@ -451,36 +447,39 @@ __global__ void __launch_bounds__(NT1, 2) k_local_attn_t1(LaParams p) {
       dsum[tid] = d;
     }
     const unsigned char* aimg = img0 + l31 * IMP + h * 16;          // + wb * 32 * IMP + c * 64 + kk * 32
-    auto gchunk = [&](auto cic, auto loadb) {
-      constexpr int C = decltype(cic)::value, SET = C % 3;
+    auto gram_step = [&](int c, auto loadb) {
       constexpr bool LOADB = decltype(loadb)::value;
-      frag fa[2][2];
+      frag fa[2][2][2];
 #pragma unroll
-      for (int wb = 0; wb < 2; ++wb)
+      for (int u = 0; u < 2; ++u)
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) fa[wb][kk] = O::ld(aimg + wb * 32 * IMP + C * CB + kk * 32);
+        for (int wb = 0; wb < 2; ++wb)
 #pragma unroll
-      for (int kk = 0; kk < 2; ++kk)
+          for (int kk = 0; kk < 2; ++kk) fa[u][wb][kk] = O::ld(aimg + wb * 32 * IMP + (c + u) * CB + kk * 32);
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-          O::mma(fa[0][kk], bq[SET][j][kk], acc0[j]);
-          O::mma(fa[1][kk], bq[SET][j][kk], acc1[j]);
+      for (int u = 0; u < 2; ++u) {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+          for (int j = 0; j < 3; ++j) {
+            O::mma(fa[u][0][kk], bq[u][j][kk], acc0[j]);
+            O::mma(fa[u][1][kk], bq[u][j][kk], acc1[j]);
+          }
+        if (LOADB && !GLR_SKIP(32)) {
+          const unsigned char* bn = gp + (size_t)(c + 2 + u) * bstep;
+#pragma unroll
+          for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) bq[u][j][kk] = ldg(bn + j * 8192 + kk * 1024);
         }
-      if (LOADB && !GLR_SKIP(32)) {
-        const unsigned char* bn = gp + (size_t)(C + 3) * bstep;
-#pragma unroll
-        for (int j = 0; j < 3; ++j)
-#pragma unroll
-          for (int kk = 0; kk < 2; ++kk) bq[SET][j][kk] = ldg(bn + j * 8192 + kk * 1024);
       }
     };
-    static_assert(SP * ESZ / CB == 12, "the Gram stream is written out for 12 chunks");
+    constexpr int nch2 = SP * ESZ / CB;
     if (!GLR_SKIP(8)) {
-      gchunk(GLR_CI(0), T{}); gchunk(GLR_CI(1), T{}); gchunk(GLR_CI(2), T{}); gchunk(GLR_CI(3), T{});
-      gchunk(GLR_CI(4), T{}); gchunk(GLR_CI(5), T{}); gchunk(GLR_CI(6), T{}); gchunk(GLR_CI(7), T{});
-      gchunk(GLR_CI(8), T{}); gchunk(GLR_CI(9), F{}); gchunk(GLR_CI(10), F{}); gchunk(GLR_CI(11), F{});
+      int c = 0;
+      for (; c + 4 <= nch2; c += 2) gram_step(c, T{});
+      gram_step(c, F{});                          // the last two chunks: nothing left to fetch
     }
-#undef GLR_CI
   }
 
   // ================= P4: Z from the ones row, |c|^2, cosine, per-sentence aggregate, maps =================
@@ -578,7 +577,7 @@ __global__ void __launch_bounds__(NT1, 2) k_local_attn_t1(LaParams p) {
 int glr_k1_launch_tiles(LaParams& p, int op_dtype, void* stream) {
   if (op_dtype != GLR_BF16 || p.S_pad != SP) return GLR_EINVAL;
   if (p.pair_desc == nullptr || p.S_eff >= p.S_pad || p.n_items <= 0) return GLR_EINVAL;
-  if (p.D % 384 != 0) return GLR_EINVAL;      // the score stream walks super-steps of 12 K chunks (caller: pair kernel otherwise)
+  if (p.D % 128 != 0 || p.D < 256) return GLR_EINVAL;   // the score stream walks four K chunks per iteration (caller: pair kernel otherwise)
   static const int env_ib = [] { const char* e = getenv("GLR_K1_IMG_BLOCK"); return e ? atoi(e) : 0; }();
   p.img_block = env_ib > 0 ? env_ib : 4;
   const int per_xcd = ((p.B_img + 7) / 8 + p.img_block - 1) / p.img_block * p.img_block;
