@@ -110,6 +110,9 @@ __global__ void __launch_bounds__(NT1, 2) k_local_attn_t1(LaParams p) {
   const int grp = qq / (ib * n_units), rem = qq - grp * (ib * n_units);
   const int b = (grp * ib + rem % ib) * 8 + xcd;
   if (b >= p.B_img) return;
+#ifdef GLR_ABLATE
+  if (p.dbg & 128) return;                      // what launching the grid alone costs
+#endif
   const int unit = rem / ib;
   const int item = unit >> 1, t = unit & 1;
   const int tile = p.item_tile[item] + t;

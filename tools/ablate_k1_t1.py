@@ -1,7 +1,8 @@
 """Diagnostic: cost of each phase of the 4-wave single-tile K1 forward (glr_local_attn_t1.hip) from the KERNEL time (HIP
 events around the launch) of builds that SKIP phases (libglr_ablate.so, GLR_K1_DBG bit mask; results are garbage, only
 time matters).  Interleaved rounds in one process.  Bits: 1 P1 stream, 2 statistics passes, 4 P2, 8 P3 stream, 16 P4,
-32 the streams WITHOUT their B loads (what the L2 -> register path costs), 64 P1 without its A staging."""
+32 the streams WITHOUT their B loads (what the L2 -> register path costs), 64 P1 without its A staging, 128 every
+workgroup returns at once (what dispatching the grid costs)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "gloria-nlp-project_amd"))
@@ -15,9 +16,9 @@ g = torch.Generator(dev).manual_seed(1234)
 img = (torch.randn(B, 768, 19, 19, device=dev, generator=g) * 0.5).bfloat16().contiguous(memory_format=torch.channels_last)
 words = (torch.randn(B, 768, 97, device=dev, generator=g) * 0.5).bfloat16()
 lens = sorted((int(x) + 1 for x in np.random.default_rng(1234).integers(4, 40, size=B)), reverse=True)
-masks = [0, 1, 2, 4, 8, 16, 22, 9, 31, 32, 96, 32 | 22]
+masks = [0, 1, 2, 4, 8, 16, 22, 9, 31, 128, 32, 96, 32 | 22]
 names = {0: "full", 1: "-P1", 2: "-stats", 4: "-P2", 8: "-P3", 16: "-P4", 22: "-all VALU phases", 9: "-both streams",
-         31: "-everything", 32: "-B loads", 96: "-B loads -A staging", 54: "-B loads -VALU phases"}
+         31: "-everything", 128: "empty workgroups", 32: "-B loads", 96: "-B loads -A staging", 54: "-B loads -VALU phases"}
 res = {m: [] for m in masks}
 for rnd in range(3):
     for m in masks:
