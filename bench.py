@@ -408,10 +408,12 @@ def main():
                        "first_step_s": first_step_s, "train_flags": bool(args.train_flags),
                        "world_size_seen": torch.distributed.get_world_size() if dctx else 1,
                        "encoder_streams": 2 if GM.ENCODER_STREAMS else 1,
+                       "image_encoder_hipgraph": bool(model.gloria._img_graph is not None),
                        "kernel_launches_per_step": launches, "sum_cap_lens": cap_lens_sum,
                        "parallelism": f"dp{world}" + (" (text-embedding all-gather + grad all-reduce, RCCL)" if world > 1 else ""),
                        "final_loss": float(loss)},
-            "roofline": {"bound": "mfma", "kernel": "glr_local_attn_fwd (K1: k_local_attn_pw + single-tile launches)",
+            "roofline": {"bound": "mfma", "kernel": "glr_local_attn_fwd (K1: k_local_attn_t1, one 64-slot tile per 4-wave "
+                                                    "workgroup; long sentences / odd tiles: pair and single-tile kernels)",
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak if peak else None,
                          "launch_ms": k1_ms, "launches": len(prof.get("k1_fwd", [])),
                          "algorithmic_flops_per_launch": mean_flops,
