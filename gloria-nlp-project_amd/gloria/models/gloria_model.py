@@ -101,7 +101,10 @@ class GLoRIA(nn.Module):
         self.temp1, self.temp2, self.temp3 = g.temp1, g.temp2, g.temp3
         self.batch_size = cfg.train.batch_size
         self.dist = None                        # set by the trainer for data-parallel runs
-        self._img_graph, self._img_graph_shape = None, None      # set by enable_image_graph()
+        # set by enable_image_graph(); kept OUT of the module tree (object.__setattr__): the graphed callable wraps
+        # img_encoder, and a registered copy would duplicate every image-encoder key in state_dict() / checkpoints
+        object.__setattr__(self, "_img_graph", None)
+        self._img_graph_shape = None
         self.ixtoword = None                    # reference attribute (:79); strings live in text_encoder.vocab
 
     # ------------------------------------------------------------------ encoders (ref :81-103)
@@ -128,7 +131,8 @@ class GLoRIA(nn.Module):
         with torch.no_grad():
             for k, v in self.img_encoder.named_buffers():
                 v.copy_(keep[k])
-        self._img_graph, self._img_graph_shape = graphed, (tuple(sample_imgs.shape), sample_imgs.dtype)
+        object.__setattr__(self, "_img_graph", graphed)
+        self._img_graph_shape = (tuple(sample_imgs.shape), sample_imgs.dtype)
         return True
 
     def image_encoder_forward(self, imgs):

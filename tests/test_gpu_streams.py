@@ -142,6 +142,7 @@ def test_graphed_image_encoder_equals_eager():
         loss = float(tr.training_step(model, batch, 0))
         torch.cuda.synchronize()
         assert (model.gloria._img_graph is not None) == bool(graph)
+        assert not any("_img_graph" in k for k in model.state_dict())          # the capture stays out of checkpoints
         grads = {n: p.grad.float().cpu() for n, p in model.named_parameters() if p.grad is not None}
         bn = {n: b.float().cpu().clone() for n, b in model.named_buffers() if "running_" in n}
         loss2 = float(tr.training_step(model, batch, 1))

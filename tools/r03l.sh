@@ -1,6 +1,6 @@
 #!/bin/bash
 OUT=gpurun_out/r03l; mkdir -p $OUT
-timeout -k 10 900 python -m pytest tests -m gpu -x -q > $OUT/gpu_tests.log 2>&1; tail -3 $OUT/gpu_tests.log
+timeout -k 10 900 python -m pytest tests -m gpu -x -q > $OUT/gpu_tests.log 2>&1; tail -3 $OUT/gpu_tests.log | cut -c1-300
 timeout -k 10 300 python bench.py --no-cpu-baseline --steps 20 > $OUT/bench.json 2> $OUT/bench.err
 python3 - <<PY
 import json
