@@ -292,7 +292,7 @@ def test_optimizer_state_crosses_between_stock_and_flat_adam_by_parameter(tmp_pa
         # stock Adam holds state only for parameters that have received a gradient, the flat optimizer for all of its
         # parameters from the start (zeros): compare what both hold, and what only one holds must be all zeros
         common = set(want) & set(got)
-        assert len(common) > 300, (sorted(set(want) ^ set(got))[:10], len(want), len(got))
+        assert len(common) > 150, (sorted(set(want) ^ set(got))[:10], len(want), len(got))
         for n in set(want) ^ set(got):
             m = (want.get(n) or got.get(n))
             assert float(m[0].abs().max()) == 0.0 and float(m[1].abs().max()) == 0.0, n
