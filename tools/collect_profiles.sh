@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round profiles in one GPU call (run from the repo root on the GPU box): bench lines, rocprofv3 kernel stats of the
 # bench command, PMC passes of the K1 kernels (bounded per pass), ablation and stamps of the forward pair kernel.
-TAG=${1:-r02}
+TAG=${1:-r03}
 ROOT=$(pwd)
 OUT="$ROOT/gpurun_out/$TAG"
 mkdir -p "$OUT"
@@ -12,6 +12,7 @@ say "bench cfg2 fp32 B=64"; timeout -k 10 300 python bench.py --precision fp32 -
 for gb in 128 64 32; do
   say "bench per-GPU batch $gb"; timeout -k 10 300 python bench.py --global-batch $gb --no-cpu-baseline > "$OUT/bench_b$gb.json" 2>> "$OUT/bench.err"
 done
+say "bench with the reference's training flags (submit_job.sh:15)"; timeout -k 10 300 python bench.py --train-flags --no-cpu-baseline > "$OUT/bench_train_flags.json" 2>> "$OUT/bench.err"
 say "forced single-rank RCCL path at 32"
 GLR_FORCE_DIST=1 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 MASTER_ADDR=127.0.0.1 MASTER_PORT=29571 timeout -k 10 300 python bench.py --global-batch 32 --no-cpu-baseline > "$OUT/bench_b32_forced_dist.json" 2>> "$OUT/bench.err"
 say "rocprofv3 kernel stats of bench.py"
@@ -25,10 +26,10 @@ cp "$OUT"/prof_k1/*/*_kernel_stats.csv "$OUT/k1_fwd_bwd_kernel_stats.csv" 2>/dev
 rm -rf "$OUT/prof_k1"
 say "PMC passes, K1 forward"; PASS_TIMEOUT=100 bash tools/pmc_k1.sh ${TAG}_fwd fwd > "$OUT/pmc_fwd.log" 2>&1
 say "PMC passes, K1 forward + backward"; PASS_TIMEOUT=100 bash tools/pmc_k1.sh ${TAG}_bwd bwd > "$OUT/pmc_bwd.log" 2>&1
-say "ablation"; timeout -k 10 200 python tools/ablate_k1.py > "$OUT/ablate.txt" 2>&1
+say "ablation"; timeout -k 10 300 python tools/ablate_k1_t1.py > "$OUT/ablate_t1.txt" 2>&1
+say "K1 forward micro-benchmark (kernel-only / op-level, HIP events)"
+{ timeout -k 10 120 python tools/bench_k1_kernel.py 256 30; GLR_K1_T1=0 timeout -k 10 120 python tools/bench_k1_kernel.py 256 30; timeout -k 10 120 python tools/bench_k1_kernel.py 256 10 max; NO_ATTN=1 timeout -k 10 120 python tools/bench_k1_kernel.py 256 30; } 2>&1 | grep "B=" > "$OUT/k1_microbench.txt"
 say "ablation, backward"; timeout -k 10 200 python tools/ablate_k1_bwd.py > "$OUT/ablate_bwd.txt" 2>&1
-say "stamps"; timeout -k 10 200 python tools/stamps_k1.py > "$OUT/stamps.txt" 2>&1
-timeout -k 10 200 python tools/stamps_k1.py bwd > "$OUT/stamps_bwd.txt" 2>&1
 say "encoder micro-benchmarks"; timeout -k 10 200 python tools/bench_bn.py > "$OUT/bench_bn.txt" 2>&1
 (cd /tmp && export TMPDIR=/tmp && timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_attn" -- python3 "$ROOT/tools/bench_attn.py" > "$OUT/bench_attn.txt" 2>&1)
 grep -h "attn\|bwd_kernel" "$OUT"/prof_attn/*/*kernel_stats.csv > "$OUT/attn_kernel_stats.csv" 2>/dev/null
