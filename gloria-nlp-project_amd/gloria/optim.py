@@ -72,22 +72,24 @@ class _Group:
             tab[k] = e
         self.n_chunks = len(ent)
         self.table = torch.from_numpy(tab.view(np.uint8).copy()).to(device)
-        # two pinned staging buffers used alternately + an event: the host may not rewrite a buffer whose
-        # asynchronous upload has not run yet
-        self.ptr_host2 = [torch.zeros(len(params), dtype=torch.int64).pin_memory() for _ in range(2)]
-        self.ptr_event = [None, None]
-        self.ptr_turn = 0
+        # pinned staging buffers, ONE PER CALL SITE (= per bucket of the data-parallel reducer, keyed by its first
+        # parameter) + an event each: the host may not rewrite a buffer whose asynchronous upload has not run yet, and
+        # with a buffer of its own a bucket only ever waits for its OWN upload of the previous step - long done.  (Two
+        # buffers used alternately made the third bucket of a step wait for the first one's upload, i.e. for the GPU to
+        # reach it: the host could not run ahead of the backward pass - 14 ms inside run_backward at 32 pairs per rank.)
+        self.ptr_stage = {}
         self.ptr_dev = torch.zeros(len(params), dtype=torch.int64, device=device)
         self._keep = []
 
     def stage_grad_pointers(self, i0=0, i1=None):
         """addresses of this step's gradients of parameters [i0, i1) (dense, parameter strides, group dtype) -> device"""
         i1 = len(self.params) if i1 is None else i1
-        turn = self.ptr_turn
-        self.ptr_turn ^= 1
-        if self.ptr_event[turn] is not None:
-            self.ptr_event[turn].synchronize()        # the upload that last used this staging buffer has run
-        host = self.ptr_host2[turn]
+        st = self.ptr_stage.get(i0)
+        if st is None:
+            st = self.ptr_stage[i0] = [torch.zeros(len(self.params), dtype=torch.int64).pin_memory(), None]
+        if st[1] is not None:
+            st[1].synchronize()                       # the upload that last used this staging buffer has run
+        host = st[0]
         keep = []
         for i in range(i0, i1):
             p = self.params[i]
@@ -103,7 +105,7 @@ class _Group:
         self.ptr_dev[i0:i1].copy_(host[i0:i1], non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
-        self.ptr_event[turn] = ev
+        st[1] = ev
 
     def gather(self, i0, i1):
         """data-parallel: the gradients of parameters [i0, i1) -> their slots of the flat gradient buffer (one launch),
