@@ -133,11 +133,16 @@ class GradReducer:
     all buckets.  xGMI is point-to-point: few large buckets (64 MiB) keep RCCL on all links."""
 
     @classmethod
-    def from_flat(cls, groups, ctx, bucket_bytes=64 << 20):
+    def from_flat(cls, groups, ctx, bucket_bytes=64 << 20, overlap=True):
         """groups: the parameter groups of a flat optimizer (gloria.optim.ShadowAdam, flat_grads=True).  A bucket is a
         run of consecutive parameters of one group (>= bucket_bytes of gradient); when its last gradient arrives the
         group gathers the bucket's gradients into the flat buffer with ONE launch (`group.gather`) and the slice is
-        all-reduced asynchronously while backward keeps running."""
+        all-reduced asynchronously while backward keeps running.
+        overlap=False: no hooks at all - `finish()` gathers each group with one launch and all-reduces it whole.  At
+        small per-rank batches the step is bound by HOST time, and ~360 Python hook calls + 5 bucket launches from
+        autograd's device thread (2.7 ms per step at 32 pairs) cost more than hiding a ~1 ms all-reduce buys."""
+        if not overlap:
+            bucket_bytes = float("inf")
         self = cls.__new__(cls)
         self.ctx, self.buckets, self._views, self._fired = ctx, [], {}, set()
         self._hide_unused = False
@@ -152,8 +157,9 @@ class GradReducer:
                     plist = g.params[start:i + 1]
                     self.buckets.append((None, plist))
                     self._flat.append((g, start, i + 1))
-                    for q in plist:
-                        q.register_post_accumulate_grad_hook(lambda _p, k=idx: self._on_ready(k, _p))
+                    if overlap:
+                        for q in plist:
+                            q.register_post_accumulate_grad_hook(lambda _p, k=idx: self._on_ready(k, _p))
                     start = i + 1
         self._pending = []
         self._ready = [0] * len(self.buckets)

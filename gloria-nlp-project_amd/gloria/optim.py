@@ -90,17 +90,18 @@ class _Group:
         if st[1] is not None:
             st[1].synchronize()                       # the upload that last used this staging buffer has run
         host = st[0]
-        keep = []
-        for i in range(i0, i1):
-            p = self.params[i]
+        keep, ptrs = [], []
+        gdt = self.gdt
+        for p in self.params[i0:i1]:
             g = p.grad
             if g is None:
-                host[i] = 0
+                ptrs.append(0)
                 continue
-            if g.dtype != self.gdt or g.stride() != p.stride():
-                g = torch.empty_strided(p.shape, p.stride(), dtype=self.gdt, device=p.device).copy_(g)
+            if g.dtype != gdt or g.stride() != p.stride():
+                g = torch.empty_strided(p.shape, p.stride(), dtype=gdt, device=p.device).copy_(g)
             keep.append(g)
-            host[i] = g.data_ptr()
+            ptrs.append(g.data_ptr())
+        host.numpy()[i0:i1] = ptrs        # one vectorised write (a tensor element store costs microseconds each)
         self._keep = keep                 # alive until the kernels that read them have been queued (same stream)
         self.ptr_dev[i0:i1].copy_(host[i0:i1], non_blocking=True)
         ev = torch.cuda.Event()

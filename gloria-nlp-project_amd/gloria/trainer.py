@@ -41,6 +41,10 @@ class Trainer:
             graph_image_encoder = (env != "0") if env is not None else not (dist_ctx is not None and dist_ctx.active)
         self.graph_image_encoder = bool(graph_image_encoder) and not self.sync_bn
         self._graph_tried = False
+        # bucketed all-reduce overlapped with backward (hooks) or one gather + all-reduce per group after it
+        # (GradReducer.from_flat); GLR_REDUCER_OVERLAP=0/1 overrides the default
+        env = os.environ.get("GLR_REDUCER_OVERLAP")
+        self.reducer_overlap = (env != "0") if env is not None else True
         # bf16 runs on the GPU keep fp32 master weights + bf16 shadows in flat buffers and do clip + Adam in three
         # launches (gloria/optim.py); GLR_FLAT_OPTIMIZER=0 or flat_optimizer=False keeps torch's fused Adam + autocast casts
         if flat_optimizer is None:
@@ -76,7 +80,7 @@ class Trainer:
         if self.dist is not None and self.dist.active:
             from .dist import GradReducer
             if self.flat:       # the optimizer's flat gradient buffers are the all-reduce buckets
-                self.reducer = GradReducer.from_flat(self.optimizer.groups, self.dist)
+                self.reducer = GradReducer.from_flat(self.optimizer.groups, self.dist, overlap=self.reducer_overlap)
             else:
                 self.reducer = GradReducer(self.params, self.dist)      # grads become views of flat buckets
         return model

@@ -23,6 +23,31 @@ for _ in range(10):
     trainer.training_step(model, batch)
 torch.cuda.synchronize()
 print(f"step {1e3 * (time.perf_counter() - t0) / 10:.2f} ms (dist={dctx is not None})")
+# time spent inside the reducer's hooks (they run on autograd's device thread, which cProfile does not see)
+if trainer.reducer is not None:
+    from gloria import dist as D, optim as OPT
+    acc = {}
+    def timed(obj, name):
+        f = getattr(obj, name)
+        def w(*a, **k):
+            t = time.perf_counter()
+            try:
+                return f(*a, **k)
+            finally:
+                acc[name] = acc.get(name, 0.0) + time.perf_counter() - t
+                acc[name + "_n"] = acc.get(name + "_n", 0) + 1
+        setattr(obj, name, w)
+    timed(trainer.reducer, "_on_ready"); timed(trainer.reducer, "_reduce_bucket"); timed(trainer.reducer, "_join_streams")
+    timed(trainer.reducer, "finish"); timed(trainer.reducer, "zero_grad")
+    for g in trainer.optimizer.groups:
+        timed(g, "gather"); timed(g, "stage_grad_pointers")
+    import torch.distributed as tdist
+    timed(tdist, "all_reduce"); timed(tdist, "reduce_scatter_tensor"); timed(tdist, "all_gather_into_tensor")
+    # hooks were registered with the bound method: re-point them through the instance attribute
+    for _ in range(10):
+        trainer.training_step(model, batch)
+    torch.cuda.synchronize()
+    print("reducer host time per step (ms):", {k: (round(v / 10 * 1e3, 3) if not k.endswith("_n") else v // 10) for k, v in sorted(acc.items())})
 pr = cProfile.Profile()
 pr.enable()
 for _ in range(10):
