@@ -32,19 +32,20 @@ class Trainer:
         # section 7); the default keeps per-rank statistics (speed mode)
         self.sync_bn = bool(sync_bn)
         # hipGraph capture of the image encoder's forward + backward at the first training step (GLoRIA.enable_image_graph):
-        # on by default in single-process training (81.1 -> 79.7 ms per step at 256 pairs, 20.5 -> 18.5 ms at 32); off
-        # under data parallelism, where it measured no gain (21.6 vs 22.0 ms on the single-rank RCCL path: the reducer's
-        # hooks then fire in one burst behind the replay), and with SyncBatchNorm (a collective inside the capture).
-        # GLR_GRAPH_IMG=0/1 overrides.
+        # 81.1 -> 79.7 ms per step at 256 pairs, 20.5 -> 18.5 ms at 32 (single process); on the data-parallel path at 32
+        # pairs per rank 27.7 -> 20.3 ms with the hook-driven reducer and 16.1 ms with the hook-free one (below).  Off
+        # with SyncBatchNorm (a collective inside the capture).  GLR_GRAPH_IMG=0/1 overrides.
         if graph_image_encoder is None:
-            env = os.environ.get("GLR_GRAPH_IMG")
-            graph_image_encoder = (env != "0") if env is not None else not (dist_ctx is not None and dist_ctx.active)
+            graph_image_encoder = os.environ.get("GLR_GRAPH_IMG", "1") != "0"
         self.graph_image_encoder = bool(graph_image_encoder) and not self.sync_bn
         self._graph_tried = False
         # bucketed all-reduce overlapped with backward (hooks) or one gather + all-reduce per group after it
         # (GradReducer.from_flat); GLR_REDUCER_OVERLAP=0/1 overrides the default
+        # Default: overlap from 64 pairs per rank on.  Below that the step is bound by HOST time and the hooks (~360
+        # Python calls + 5 bucket launches from autograd's device thread) cost more than hiding a ~1.4 ms all-reduce
+        # buys: 20.3 ms with hooks against 16.1 ms without at 32 pairs per rank (single-rank RCCL rehearsal, one GPU).
         env = os.environ.get("GLR_REDUCER_OVERLAP")
-        self.reducer_overlap = (env != "0") if env is not None else True
+        self.reducer_overlap = (env != "0") if env is not None else int(cfg.train.batch_size or 0) >= 64
         # bf16 runs on the GPU keep fp32 master weights + bf16 shadows in flat buffers and do clip + Adam in three
         # launches (gloria/optim.py); GLR_FLAT_OPTIMIZER=0 or flat_optimizer=False keeps torch's fused Adam + autocast casts
         if flat_optimizer is None:
