@@ -155,3 +155,24 @@ def test_graphed_image_encoder_equals_eager():
         return loss, loss2, grads, bn
 
     _compare(run(False), run(True))
+
+
+def test_hook_free_reducer_equals_hook_driven_reducer(monkeypatch):
+    """one gather + all-reduce per parameter group behind backward (GLR_REDUCER_OVERLAP=0: no autograd hooks) against the
+    bucketed, hook-driven reduction during backward: the same flat gradient buffers, losses and BatchNorm statistics"""
+    import torch.distributed as dist
+    from gloria import dist as gdist
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    for k, v in dict(GLR_FORCE_DIST="1", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+                     MASTER_PORT=str(port)).items():
+        monkeypatch.setenv(k, v)
+    try:
+        dctx = gdist.init_from_env("nccl")
+        monkeypatch.setenv("GLR_REDUCER_OVERLAP", "1")
+        hooked = _run(True, dctx)
+        monkeypatch.setenv("GLR_REDUCER_OVERLAP", "0")
+        free = _run(True, dctx)
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+    _compare(hooked, free)
