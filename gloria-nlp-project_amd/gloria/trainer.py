@@ -41,11 +41,12 @@ class Trainer:
         self._graph_tried = False
         # bucketed all-reduce overlapped with backward (hooks) or one gather + all-reduce per group after it
         # (GradReducer.from_flat); GLR_REDUCER_OVERLAP=0/1 overrides the default
-        # Default: overlap from 64 pairs per rank on.  Below that the step is bound by HOST time and the hooks (~360
-        # Python calls + 5 bucket launches from autograd's device thread) cost more than hiding a ~1.4 ms all-reduce
-        # buys: 20.3 ms with hooks against 16.1 ms without at 32 pairs per rank (single-rank RCCL rehearsal, one GPU).
-        env = os.environ.get("GLR_REDUCER_OVERLAP")
-        self.reducer_overlap = (env != "0") if env is not None else int(cfg.train.batch_size or 0) >= 64
+        # Default: NO overlap.  Measured on the single-rank RCCL rehearsal (one GPU, image-encoder graph on) the
+        # hook-driven reducer costs ~5 ms per step at every per-rank batch - 20.3 vs 16.1 ms at 32 pairs, 29.3 vs 24.6 at
+        # 64, 47.9 vs 42.2 at 128 (~360 Python hook calls and 5 bucket launches from autograd's device thread, and the
+        # accumulate-grad nodes it keeps alive across steps) - against the ~1.4 ms a 268-MB bf16 all-reduce takes on
+        # 8 GPUs when nothing hides it.
+        self.reducer_overlap = (env != "0") if env is not None else False
         # bf16 runs on the GPU keep fp32 master weights + bf16 shadows in flat buffers and do clip + Adam in three
         # launches (gloria/optim.py); GLR_FLAT_OPTIMIZER=0 or flat_optimizer=False keeps torch's fused Adam + autocast casts
         if flat_optimizer is None:

@@ -82,7 +82,7 @@ def test_two_stream_encoders_under_the_data_parallel_reducer(monkeypatch, overla
     """the reducer joins the streams that produced a bucket's gradients before it gathers and all-reduces the bucket
     (gloria.dist.GradReducer._join_streams): same flat gradient buffers with one stream and with two - with the
     hook-driven reducer (buckets all-reduced during backward) and with the hook-free one (one gather + all-reduce per
-    group behind backward, the default below 64 pairs per rank)"""
+    group behind backward, the default)"""
     monkeypatch.setenv("GLR_REDUCER_OVERLAP", overlap)
     import torch.distributed as dist
     from gloria import dist as gdist
