@@ -419,9 +419,14 @@ def main():
                          "algorithmic_flops_per_launch": mean_flops,
                          # whole forward op: operand packing + Gram GEMM + K-tiling + K1 (same algorithmic FLOPs)
                          "op_ms": k1_op_ms, "achieved_op": achieved_op, "frac_op": achieved_op / peak if peak else None,
-                         # HBM-side bytes per launch come from the rocprofv3 PMC passes committed under profiles/
-                         # (FETCH_SIZE in its own pass, x2 gfx950 correction); not measured by this run
-                         "traffic": None},
+                         # HBM-side bytes per launch: NOT measured by this run (PMC needs its own rocprofv3 passes); for the
+                         # metric's workload the committed pass profiles/r03_k1_pmc_counters_fwd.txt gives FETCH_SIZE
+                         # 743 172 KB x 2 (gfx950 correction) + WRITE_SIZE 1.4 MB = 1.49 GB per launch against 160 MB of
+                         # operands + outputs (235 MB with the Gram matrices)
+                         "traffic": 1.49e9 if (GB == GLOBAL_BATCH and world == 1 and args.lengths == "words"
+                                               and args.precision == "bf16" and not args.train_flags) else None,
+                         "traffic_source": "profiles/r03_k1_pmc_counters_fwd.txt (separate rocprofv3 --pmc passes of "
+                                           "tools/prof_k1.py at the same shape; FETCH_SIZE x 2 + WRITE_SIZE)"},
             "loss_path": {"k1_bwd_launch_ms": k1_bwd_ms, "k1_bwd_op_ms": k1_bwd_op_ms,
                           "k1_bwd_library_gemm_share": (1.0 - k1_bwd_ms / k1_bwd_op_ms) if (k1_bwd_ms and k1_bwd_op_ms) else None},
         }
