@@ -46,6 +46,7 @@ class Trainer:
         # 64, 47.9 vs 42.2 at 128 (~360 Python hook calls and 5 bucket launches from autograd's device thread, and the
         # accumulate-grad nodes it keeps alive across steps) - against the ~1.4 ms a 268-MB bf16 all-reduce takes on
         # 8 GPUs when nothing hides it.
+        env = os.environ.get("GLR_REDUCER_OVERLAP")
         self.reducer_overlap = (env != "0") if env is not None else False
         # bf16 runs on the GPU keep fp32 master weights + bf16 shadows in flat buffers and do clip + Adam in three
         # launches (gloria/optim.py); GLR_FLAT_OPTIMIZER=0 or flat_optimizer=False keeps torch's fused Adam + autocast casts
