@@ -112,7 +112,8 @@ __global__ void __launch_bounds__(LN_NT) k_drop_add_ln_fwd(const unsigned short*
 }
 
 // backward: dz = rstd (g dy - mean(g dy) - xhat mean(g dy xhat)); d_inp = dz; d_h = dz * keep / (1 - p);
-// dgamma += dy xhat, dbeta += dy (per-wave registers -> per-workgroup partial [2][H][n_part])
+// dgamma += dy xhat, dbeta += dy, dhsum += d_h (per-wave registers -> per-workgroup partial [3][H][n_part]); dhsum is
+// the bias gradient of the dense Linear that produced h (its column sums would otherwise be one more pass over d_h)
 template <int NQ>
 __global__ void __launch_bounds__(LN_NT) k_drop_add_ln_bwd(const float* __restrict__ dy32, const unsigned short* __restrict__ dy16,
                                                            const unsigned short* __restrict__ h, const float* __restrict__ inp,
@@ -124,13 +125,13 @@ __global__ void __launch_bounds__(LN_NT) k_drop_add_ln_bwd(const float* __restri
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const bool drop = p_drop > 0.f;
   const float inv_keep = drop ? 1.f / (1.f - p_drop) : 1.f;
-  float g[NQ][4], dg[NQ][4], db[NQ][4];
+  float g[NQ][4], dg[NQ][4], db[NQ][4], dhs[NQ][4];
 #pragma unroll
   for (int i = 0; i < NQ; ++i) {
     const float4 gv = *reinterpret_cast<const float4*>(gamma + 4 * (lane + 64 * i));
     g[i][0] = gv.x; g[i][1] = gv.y; g[i][2] = gv.z; g[i][3] = gv.w;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) { dg[i][c] = 0.f; db[i][c] = 0.f; }
+    for (int c = 0; c < 4; ++c) { dg[i][c] = 0.f; db[i][c] = 0.f; dhs[i][c] = 0.f; }
   }
   for (long long row = (long long)blockIdx.x * (LN_NT / 64) + wv; row < R; row += (long long)gridDim.x * (LN_NT / 64)) {
     const float mean = stats[row * 2], rstd = stats[row * 2 + 1];
@@ -182,42 +183,120 @@ __global__ void __launch_bounds__(LN_NT) k_drop_add_ln_bwd(const float* __restri
       for (int c = 0; c < 4; ++c) {
         dz[c] = rstd * (gd[i][c] - m1 - xh[i][c] * m2);
         dh[c] = ((keepbits[i] >> c) & 1u) ? dz[c] * inv_keep : 0.f;
+        dhs[i][c] += dh[c];
       }
       *reinterpret_cast<float4*>(d_inp + row * H + 4 * quad) = make_float4(dz[0], dz[1], dz[2], dz[3]);
       *reinterpret_cast<uint2*>(d_h + row * H + 4 * quad) = pack4(dh);
     }
   }
   // the workgroup's four waves -> one partial per column (fixed order)
-  __shared__ float red[2][LN_NT / 64][H];
+  __shared__ float red[3][LN_NT / 64][H];
 #pragma unroll
   for (int i = 0; i < NQ; ++i)
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       red[0][wv][4 * (lane + 64 * i) + c] = dg[i][c];
       red[1][wv][4 * (lane + 64 * i) + c] = db[i][c];
+      red[2][wv][4 * (lane + 64 * i) + c] = dhs[i][c];
     }
   __syncthreads();
   for (int col = threadIdx.x; col < H; col += LN_NT) {
-    float a = 0.f, b = 0.f;
+    float a = 0.f, b = 0.f, e = 0.f;
 #pragma unroll
-    for (int k = 0; k < LN_NT / 64; ++k) { a += red[0][k][col]; b += red[1][k][col]; }
+    for (int k = 0; k < LN_NT / 64; ++k) { a += red[0][k][col]; b += red[1][k][col]; e += red[2][k][col]; }
     part[(size_t)col * gridDim.x + blockIdx.x] = a;
     part[((size_t)H + col) * gridDim.x + blockIdx.x] = b;
+    part[((size_t)2 * H + col) * gridDim.x + blockIdx.x] = e;
   }
 }
 
-// second stage: one wave per column sums its partials of both quantities in a fixed order
+// second stage: one wave per column sums its partials of the three quantities in a fixed order
 __global__ void __launch_bounds__(LN_NT) k_ln_finish(const float* __restrict__ part, int n_part, int H, float* __restrict__ dgamma,
-                                                     float* __restrict__ dbeta) {
+                                                     float* __restrict__ dbeta, void* __restrict__ dhsum, int dhsum_bf16) {
   const int lane = threadIdx.x & 63;
   const int col = blockIdx.x * (LN_NT / 64) + (threadIdx.x >> 6);
   if (col >= H) return;
-  float a = 0.f, b = 0.f;
-  for (int k = lane; k < n_part; k += 64) { a += part[(size_t)col * n_part + k]; b += part[((size_t)H + col) * n_part + k]; }
+  float a = 0.f, b = 0.f, e = 0.f;
+  for (int k = lane; k < n_part; k += 64) {
+    a += part[(size_t)col * n_part + k];
+    b += part[((size_t)H + col) * n_part + k];
+    if (dhsum) e += part[((size_t)2 * H + col) * n_part + k];
+  }
   a = wave_sum_f(a);
   b = wave_sum_f(b);
-  if (lane == 0) { dgamma[col] = a; dbeta[col] = b; }
+  e = wave_sum_f(e);
+  if (lane == 0) {
+    dgamma[col] = a;
+    dbeta[col] = b;
+    if (dhsum) {
+      if (dhsum_bf16) reinterpret_cast<unsigned short*>(dhsum)[col] = f2bf(e);
+      else reinterpret_cast<float*>(dhsum)[col] = e;
+    }
+  }
 }
+
+// Column sums of a bf16 [R, C] matrix (bias gradient of a Linear: sum over tokens of dy): thread = 8 columns x every 8th
+// row of its workgroup's row slab, LDS reduction over the 8 row lanes, partial [C][n_part], fixed-order second stage.
+// HBM-bound, 2 bytes per element; aten's generic reduce_kernel runs these shapes at 0.7 - 2.7 TB/s.
+constexpr int CS_COLS = 256;           // columns per workgroup (32 threads x 8)
+__global__ void __launch_bounds__(LN_NT) k_colsum(const unsigned short* __restrict__ x, long long R, int C, long long rows_per,
+                                                   float* __restrict__ part) {
+  const int ct = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int col0 = blockIdx.x * CS_COLS + ct * 8;
+  const long long r0 = (long long)blockIdx.y * rows_per;
+  const long long r1 = r0 + rows_per < R ? r0 + rows_per : R;
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const unsigned short* px = x + col0;
+  long long r = r0 + rl;
+  for (; r + 24 < r1; r += 32) {
+    uint4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const uint4*>(px + (r + 8 * u) * C);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      acc[0] += __uint_as_float(v[u].x << 16); acc[1] += __uint_as_float(v[u].x & 0xffff0000u);
+      acc[2] += __uint_as_float(v[u].y << 16); acc[3] += __uint_as_float(v[u].y & 0xffff0000u);
+      acc[4] += __uint_as_float(v[u].z << 16); acc[5] += __uint_as_float(v[u].z & 0xffff0000u);
+      acc[6] += __uint_as_float(v[u].w << 16); acc[7] += __uint_as_float(v[u].w & 0xffff0000u);
+    }
+  }
+  for (; r < r1; r += 8) {
+    const uint4 v = *reinterpret_cast<const uint4*>(px + r * C);
+    acc[0] += __uint_as_float(v.x << 16); acc[1] += __uint_as_float(v.x & 0xffff0000u);
+    acc[2] += __uint_as_float(v.y << 16); acc[3] += __uint_as_float(v.y & 0xffff0000u);
+    acc[4] += __uint_as_float(v.z << 16); acc[5] += __uint_as_float(v.z & 0xffff0000u);
+    acc[6] += __uint_as_float(v.w << 16); acc[7] += __uint_as_float(v.w & 0xffff0000u);
+  }
+  __shared__ float red[8][CS_COLS + 8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) red[rl][ct * 8 + c] = acc[c];
+  __syncthreads();
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) s += red[k][threadIdx.x];
+  part[(size_t)(blockIdx.x * CS_COLS + threadIdx.x) * gridDim.y + blockIdx.y] = s;
+}
+
+__global__ void __launch_bounds__(LN_NT) k_colsum_finish(const float* __restrict__ part, int n_part, int C, void* __restrict__ out,
+                                                          int out_bf16) {
+  const int lane = threadIdx.x & 63;
+  const int col = blockIdx.x * (LN_NT / 64) + (threadIdx.x >> 6);
+  if (col >= C) return;
+  float a = 0.f;
+  for (int k = lane; k < n_part; k += 64) a += part[(size_t)col * n_part + k];
+  a = wave_sum_f(a);
+  if (lane == 0) {
+    if (out_bf16) reinterpret_cast<unsigned short*>(out)[col] = f2bf(a);
+    else reinterpret_cast<float*>(out)[col] = a;
+  }
+}
+int colsum_parts(long long R, int C) {
+  long long np = 1024 / (C / CS_COLS);                 // ~4 workgroups per CU over the whole grid
+  if (np < 1) np = 1;
+  const long long max_np = (R + 31) / 32;             // at least 32 rows per workgroup
+  return (int)(np < max_np ? np : max_np);
+}
+bool colsum_shape_ok(long long R, int C) { return R > 0 && C >= CS_COLS && C % CS_COLS == 0 && C <= 16384; }
 
 constexpr int LN_MAX_PART = 1024;      // workgroups of the backward pass (4 per CU: all resident at once)
 int ln_parts(long long R) {
@@ -228,7 +307,21 @@ bool ln_shape_ok(long long R, int H) { return R > 0 && H >= 256 && H <= 1024 && 
 
 }  // namespace
 
-extern "C" int glr_ln_workspace_floats(long long R, int H) { return ln_shape_ok(R, H) ? ln_parts(R) * 2 * H : 0; }
+extern "C" int glr_ln_workspace_floats(long long R, int H) { return ln_shape_ok(R, H) ? ln_parts(R) * 3 * H : 0; }
+
+extern "C" int glr_colsum_workspace_floats(long long R, int C) { return colsum_shape_ok(R, C) ? colsum_parts(R, C) * C : 0; }
+
+extern "C" int glr_colsum_bf16(const void* x16, long long R, int C, float* workspace, void* out, int out_bf16, void* stream) {
+  if (!x16 || !workspace || !out || !colsum_shape_ok(R, C)) return GLR_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const int np = colsum_parts(R, C);
+  const long long rows_per = (R + np - 1) / np;
+  hipLaunchKernelGGL(k_colsum, dim3(C / CS_COLS, np), dim3(LN_NT), 0, st, (const unsigned short*)x16, R, C, rows_per, workspace);
+  GLR_CHECK_LAUNCH();
+  hipLaunchKernelGGL(k_colsum_finish, dim3((C + LN_NT / 64 - 1) / (LN_NT / 64)), dim3(LN_NT), 0, st, workspace, np, C, out, out_bf16);
+  GLR_CHECK_LAUNCH();
+  return GLR_OK;
+}
 
 extern "C" int glr_drop_add_ln_fwd(const void* h16, const float* inp32, const float* gamma, const float* beta, long long R, int H,
                                    float eps, float p_drop, unsigned long long seed, unsigned long long offset, float* out32,
@@ -253,7 +346,8 @@ extern "C" int glr_drop_add_ln_fwd(const void* h16, const float* inp32, const fl
 
 extern "C" int glr_drop_add_ln_bwd(const float* dy32, const void* dy16, const void* h16, const float* inp32, const float* gamma,
                                    const float* stats, const unsigned long long* mask, long long R, int H, float p_drop,
-                                   float* d_inp32, void* d_h16, float* workspace, float* dgamma, float* dbeta, void* stream) {
+                                   float* d_inp32, void* d_h16, float* workspace, float* dgamma, float* dbeta, void* dhsum,
+                                   int dhsum_bf16, void* stream) {
   if ((!dy32 && !dy16) || !h16 || !inp32 || !gamma || !stats || !d_inp32 || !d_h16 || !workspace || !dgamma || !dbeta ||
       !ln_shape_ok(R, H))
     return GLR_EINVAL;
@@ -271,7 +365,8 @@ extern "C" int glr_drop_add_ln_bwd(const float* dy32, const void* dy16, const vo
   }
 #undef GLR_LN_BWD
   GLR_CHECK_LAUNCH();
-  hipLaunchKernelGGL(k_ln_finish, dim3((H + LN_NT / 64 - 1) / (LN_NT / 64)), dim3(LN_NT), 0, st, workspace, np, H, dgamma, dbeta);
+  hipLaunchKernelGGL(k_ln_finish, dim3((H + LN_NT / 64 - 1) / (LN_NT / 64)), dim3(LN_NT), 0, st, workspace, np, H, dgamma, dbeta, dhsum,
+                     dhsum_bf16);
   GLR_CHECK_LAUNCH();
   return GLR_OK;
 }

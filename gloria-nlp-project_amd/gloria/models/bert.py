@@ -9,7 +9,8 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .fused_attn import packed_fusable, self_attention, self_attention_packed
-from .fused_ln import drop_add_ln
+from .fused_linear import linear
+from .fused_ln import dense_drop_add_ln
 
 
 class BertConfig:
@@ -63,7 +64,7 @@ class BertSelfAttention(nn.Module):
             # under 200 TFLOP/s), and the kernels read / write the packed tensor in place: no split, no gradient adds
             w = torch.cat([self.query.weight, self.key.weight, self.value.weight], 0)
             b_ = torch.cat([self.query.bias, self.key.bias, self.value.bias], 0)
-            return self_attention_packed(F.linear(x, w, b_), key_mask, self.nh, self.p, self.training)
+            return self_attention_packed(linear(x, w, b_), key_mask, self.nh, self.p, self.training)
         return self_attention(self.query(x), self.key(x), self.value(x), key_mask, self.nh, self.p, self.training)
 
 
@@ -76,7 +77,7 @@ class BertSelfOutput(nn.Module):
 
     def forward(self, h, inp):
         # (y fp32, y bf16 | None): dropout + residual + LayerNorm in one HIP pass under bf16 autocast (models/fused_ln.py)
-        return drop_add_ln(self.dense(h), inp, self.LayerNorm, self.dropout.p, self.training)
+        return dense_drop_add_ln(self.dense, h, inp, self.LayerNorm, self.dropout.p, self.training)
 
 
 class BertAttention(nn.Module):
@@ -96,7 +97,7 @@ class BertIntermediate(nn.Module):
         self.dense = nn.Linear(c.hidden_size, c.intermediate_size)
 
     def forward(self, x):
-        return F.gelu(self.dense(x))
+        return F.gelu(linear(x, self.dense.weight, self.dense.bias))
 
 
 class BertOutput(nn.Module):
@@ -107,7 +108,7 @@ class BertOutput(nn.Module):
         self.dropout = nn.Dropout(c.hidden_dropout_prob)
 
     def forward(self, h, inp):
-        return drop_add_ln(self.dense(h), inp, self.LayerNorm, self.dropout.p, self.training)
+        return dense_drop_add_ln(self.dense, h, inp, self.LayerNorm, self.dropout.p, self.training)
 
 
 class BertLayer(nn.Module):

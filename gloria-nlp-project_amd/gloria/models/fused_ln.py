@@ -46,7 +46,9 @@ def _philox_args(dev):
 
 class _DropAddLN(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, h, inp, weight, bias, eps, p):
+    def forward(ctx, h, inp, weight, bias, eps, p, h_bias=None):
+        # h_bias: the bias of the Linear that produced h, handed in only to RECEIVE its gradient (column sums of d_h,
+        # accumulated by the backward kernel on its way) - see fused_linear.linear(..., bias_grad_from_epilogue=True)
         L = N.lib()
         H = h.shape[-1]
         R = h.numel() // H
@@ -60,6 +62,7 @@ class _DropAddLN(torch.autograd.Function):
                                       N.ptr(out32), N.ptr(out16), N.ptr(stats), N.ptr(mask), N.stream()), "glr_drop_add_ln_fwd")
         ctx.save_for_backward(h, inp, weight, stats, mask)
         ctx.p = float(p)
+        ctx.hb = None if h_bias is None else (h_bias.dtype, h_bias.shape)
         ctx.set_materialize_grads(False)
         return out32, out16
 
@@ -71,7 +74,7 @@ class _DropAddLN(torch.autograd.Function):
         R = h.numel() // H
         dev = h.device
         if d32 is None and d16 is None:
-            return None, None, None, None, None, None
+            return None, None, None, None, None, None, None
         if d32 is not None:
             d32 = d32.float().contiguous()
         if d16 is not None:
@@ -80,10 +83,16 @@ class _DropAddLN(torch.autograd.Function):
         d_h = torch.empty(h.shape, dtype=torch.bfloat16, device=dev)
         dgb = torch.empty(2, H, dtype=torch.float32, device=dev)
         ws = _workspace(dev, R, H)
+        dhb = None
+        if ctx.hb is not None and ctx.needs_input_grad[6]:
+            if ctx.hb[0] not in (torch.bfloat16, torch.float32) or tuple(ctx.hb[1]) != (H,):
+                raise RuntimeError("drop_add_ln: h_bias must be a bf16 / fp32 vector of the hidden size")
+            dhb = torch.empty(H, dtype=ctx.hb[0], device=dev)
         N.check(L.glr_drop_add_ln_bwd(N.ptr(d32), N.ptr(d16), N.ptr(h), N.ptr(inp), N.ptr(weight), N.ptr(stats), N.ptr(mask), R, H,
-                                      ctx.p, N.ptr(d_inp), N.ptr(d_h), N.ptr(ws), N.ptr(dgb), c_off(dgb, H), N.stream()),
+                                      ctx.p, N.ptr(d_inp), N.ptr(d_h), N.ptr(ws), N.ptr(dgb), c_off(dgb, H), N.ptr(dhb),
+                                      int(dhb is not None and dhb.dtype == torch.bfloat16), N.stream()),
                 "glr_drop_add_ln_bwd")
-        return d_h, d_inp, dgb[0], dgb[1], None, None
+        return d_h, d_inp, dgb[0], dgb[1], None, None, dhb
 
 
 def c_off(t, n_elems):
@@ -99,8 +108,25 @@ def _fusable(h, inp, ln):
             and h.is_contiguous() and inp.is_contiguous())
 
 
-def drop_add_ln(h, inp, ln, p, training):
-    """(LayerNorm(dropout(h) + inp) in fp32, the same rounded to bf16 or None)."""
+def drop_add_ln(h, inp, ln, p, training, h_bias=None):
+    """(LayerNorm(dropout(h) + inp) in fp32, the same rounded to bf16 or None).  h_bias: see _DropAddLN.forward - only
+    pass it when `fusable(h, inp, ln)` (the unfused path has no gradient to give it)."""
     if _fusable(h, inp, ln):
-        return _DropAddLN.apply(h, inp, ln.weight, ln.bias, ln.eps, p if training else 0.0)
+        return _DropAddLN.apply(h, inp, ln.weight, ln.bias, ln.eps, p if training else 0.0, h_bias)
+    if h_bias is not None:
+        raise RuntimeError("drop_add_ln: h_bias given on the unfused path")
     return ln(F.dropout(h, p, training) + inp), None
+
+
+def dense_drop_add_ln(dense, x, inp, ln, p, training):
+    """drop_add_ln(dense(x), inp, ...) of a BERT sub-layer output.  On the fused path under the bf16 flat optimizer the
+    Linear's backward skips its bias gradient and the LayerNorm backward kernel supplies it (one pass over d_h less)."""
+    from .fused_linear import linear, linear_fusable
+    H = dense.out_features
+    if (ENABLED and x.is_cuda and linear_fusable(x, dense.weight, dense.bias) and inp.dtype == torch.float32
+            and H % 256 == 0 and 256 <= H <= 1024 and ln.elementwise_affine and ln.weight.dtype == torch.float32
+            and ln.bias is not None and ln.bias.dtype == torch.float32 and tuple(ln.normalized_shape) == (H,)
+            and inp.is_contiguous() and inp.shape[:-1] == x.shape[:-1] and inp.shape[-1] == H):
+        h = linear(x, dense.weight, dense.bias, bias_grad_from_epilogue=True)
+        return _DropAddLN.apply(h, inp, ln.weight, ln.bias, ln.eps, p if training else 0.0, dense.bias)
+    return drop_add_ln(dense(x), inp, ln, p, training)

@@ -385,8 +385,13 @@ int glr_bn_act_bwd(const void* x, const void* dy, const void* dy2, const void* y
  *                       4 (l + 64 i) + c of a row is bit l of word 4 i + c  (NULL when p_drop == 0)
  *   seed / offset       Philox4x32-10 key / counter prefix: the mask is a pure function of (seed, offset, row, column)
  * bwd: dy32 / dy16 = gradients w.r.t. out32 / out16 (either may be NULL); d_inp32 fp32, d_h16 bf16, dgamma / dbeta fp32 [H];
- *      workspace: glr_ln_workspace_floats(R, H) floats (0 = shape not supported).  H in {256, 512, 768, 1024}.
+ *      dhsum (NULL = not wanted): column sums of d_h, fp32 or bf16 [H] (dhsum_bf16) - the bias gradient of the dense
+ *      Linear that produced h;  workspace: glr_ln_workspace_floats(R, H) floats (0 = shape not supported).
+ *      H in {256, 512, 768, 1024}.
  * HBM-bound: 12 bytes per element forward, 18 backward; fixed-order reductions (bitwise reproducible).
+ * glr_colsum_bf16: out[c] = sum_r x16[r, c] of a contiguous bf16 [R, C] matrix, C % 256 == 0, fp32 accumulation in a fixed
+ *      order, out fp32 or bf16 (out_bf16) - the bias gradient of the other Linears (sum over tokens of dy: torch's
+ *      linear backward does it with aten's generic reduce_kernel); workspace: glr_colsum_workspace_floats(R, C) floats.
  */
 int glr_ln_workspace_floats(long long R, int H);
 int glr_drop_add_ln_fwd(const void* h16, const float* inp32, const float* gamma, const float* beta, long long R, int H,
@@ -394,7 +399,10 @@ int glr_drop_add_ln_fwd(const void* h16, const float* inp32, const float* gamma,
                         void* out16, float* stats, unsigned long long* mask, void* stream);
 int glr_drop_add_ln_bwd(const float* dy32, const void* dy16, const void* h16, const float* inp32, const float* gamma,
                         const float* stats, const unsigned long long* mask, long long R, int H, float p_drop,
-                        float* d_inp32, void* d_h16, float* workspace, float* dgamma, float* dbeta, void* stream);
+                        float* d_inp32, void* d_h16, float* workspace, float* dgamma, float* dbeta, void* dhsum, int dhsum_bf16,
+                        void* stream);
+int glr_colsum_workspace_floats(long long R, int C);
+int glr_colsum_bf16(const void* x16, long long R, int C, float* workspace, void* out, int out_bf16, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Self-attention of the BERT text encoder for short captions (reference: BertSelfAttention of

@@ -56,8 +56,17 @@ def test_drop_add_ln_matches_torch(R, H, p):
     d_h = torch.empty(R, H, device=DEV, dtype=torch.bfloat16)
     dgb = torch.empty(2, H, device=DEV)
     ws = torch.empty(L.glr_ln_workspace_floats(R, H), device=DEV)
+    dhs = torch.empty(H, device=DEV)
+    dhs16 = torch.empty(H, device=DEV, dtype=torch.bfloat16)
     N.check(L.glr_drop_add_ln_bwd(N.ptr(d32), N.ptr(d16), N.ptr(h), N.ptr(inp), N.ptr(w), N.ptr(stats), N.ptr(mask), R, H, p,
-                                  N.ptr(d_inp), N.ptr(d_h), N.ptr(ws), N.ptr(dgb), FL.c_off(dgb, H), N.stream()), "bwd")
+                                  N.ptr(d_inp), N.ptr(d_h), N.ptr(ws), N.ptr(dgb), FL.c_off(dgb, H), N.ptr(dhs16), 1, N.stream()), "bwd")
+    N.check(L.glr_drop_add_ln_bwd(N.ptr(d32), N.ptr(d16), N.ptr(h), N.ptr(inp), N.ptr(w), N.ptr(stats), N.ptr(mask), R, H, p,
+                                  N.ptr(d_inp), N.ptr(d_h), N.ptr(ws), N.ptr(dgb), FL.c_off(dgb, H), N.ptr(dhs), 0, N.stream()), "bwd")
+    # column sums of d_h = the bias gradient of the Linear that produced h
+    ref_hs = hr.grad.sum(0)
+    scale = float(ref_hs.abs().max())
+    np.testing.assert_allclose(dhs.cpu().numpy() / scale, ref_hs.cpu().numpy() / scale, atol=2e-3)
+    np.testing.assert_allclose(dhs16.float().cpu().numpy() / scale, ref_hs.cpu().numpy() / scale, atol=1e-2)
     np.testing.assert_allclose(d_inp.cpu().numpy(), ir.grad.cpu().numpy(), rtol=2e-4, atol=2e-4)
     np.testing.assert_allclose(d_h.float().cpu().numpy(), hr.grad.cpu().numpy(), rtol=1e-2, atol=1e-2)
     scale = float(wr.grad.abs().max())
@@ -66,7 +75,7 @@ def test_drop_add_ln_matches_torch(R, H, p):
     np.testing.assert_allclose(dgb[1].cpu().numpy() / scale, br.grad.cpu().numpy() / scale, atol=1e-4)
     # only one of the two gradient streams present
     N.check(L.glr_drop_add_ln_bwd(None, N.ptr(d16), N.ptr(h), N.ptr(inp), N.ptr(w), N.ptr(stats), N.ptr(mask), R, H, p,
-                                  N.ptr(d_inp), N.ptr(d_h), N.ptr(ws), N.ptr(dgb), FL.c_off(dgb, H), N.stream()), "bwd16")
+                                  N.ptr(d_inp), N.ptr(d_h), N.ptr(ws), N.ptr(dgb), FL.c_off(dgb, H), None, 0, N.stream()), "bwd16")
     ir.grad = None
     (torch.nn.functional.layer_norm(hr.detach() * keep / (1 - p) + ir, (H,), w, b, 1e-12) * d16.float()).sum().backward()
     np.testing.assert_allclose(d_inp.cpu().numpy(), ir.grad.cpu().numpy(), rtol=2e-4, atol=2e-4)
@@ -130,3 +139,61 @@ def test_bert_fused_sublayers_match_unfused_under_autocast(monkeypatch):
         with torch.autocast("cuda", dtype=torch.bfloat16):
             outs.append(model(ids, am)[0].float())
     assert torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("R,C", [(1, 256), (37, 768), (24832, 768), (4099, 2304), (1000, 3072)])
+def test_colsum_matches_torch(R, C):
+    """glr_colsum_bf16 (bias gradient of the text encoder's Linears) against an fp64 sum of the same bf16 values"""
+    from gloria import _native as N
+    L = N.lib()
+    torch.manual_seed(R + C)
+    x = (torch.randn(R, C, device=DEV) + 0.1).bfloat16()
+    ws = torch.empty(L.glr_colsum_workspace_floats(R, C), device=DEV)
+    out = torch.empty(C, device=DEV)
+    out16 = torch.empty(C, device=DEV, dtype=torch.bfloat16)
+    N.check(L.glr_colsum_bf16(N.ptr(x), R, C, N.ptr(ws), N.ptr(out), 0, N.stream()), "colsum")
+    N.check(L.glr_colsum_bf16(N.ptr(x), R, C, N.ptr(ws), N.ptr(out16), 1, N.stream()), "colsum16")
+    ref = x.double().sum(0)
+    np.testing.assert_allclose(out.cpu().numpy(), ref.cpu().numpy(), rtol=1e-5, atol=1e-3 * R ** 0.5)
+    assert torch.equal(out16, out.bfloat16())
+    assert L.glr_colsum_workspace_floats(10, 100) == 0           # unsupported width: the host falls back to torch
+    assert L.glr_colsum_bf16(N.ptr(x), R, 100, N.ptr(ws), N.ptr(out), 0, N.stream()) != 0
+
+
+def test_bert_bf16_parameter_linears_match_autograd(monkeypatch):
+    """The training configuration of the flat optimizer (bf16 shadow weights of the Linears, fp32 LayerNorms and
+    embeddings): every parameter gradient with the colsum / LayerNorm-epilogue bias gradients against torch's own
+    linear backward (GLR_FUSED_LINEAR=0 path) on the same dropout-free model."""
+    from gloria.models import bert as B
+    from gloria.models import fused_linear as FLIN
+    torch.manual_seed(0)
+    cfg = B.BertConfig(vocab_size=1000, hidden_size=256, num_hidden_layers=2, num_attention_heads=4, intermediate_size=512,
+                       hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    model = B.BertModel(cfg).to(DEV).train()
+    for m in model.modules():
+        if isinstance(m, torch.nn.Linear):
+            m.to(torch.bfloat16)
+    ids = torch.randint(5, 1000, (6, 40), device=DEV)
+    am = torch.ones_like(ids); am[:, 30:] = 0
+    proj = torch.randn(6, 40, 256, device=DEV)
+    calls = {"n": 0}
+    real = FLIN._Linear.apply
+
+    def run(enabled):
+        monkeypatch.setattr(FLIN, "ENABLED", enabled)
+        model.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            hs = model(ids, am)[2]
+        (hs[-1].float() * proj).sum().backward()
+        return {n: p.grad.float().clone() for n, p in model.named_parameters() if p.grad is not None}
+
+    ref = run(False)
+    got = run(True)
+    assert set(ref) == set(got)
+    n_bias = 0
+    for n in ref:
+        scale = float(ref[n].abs().max()) + 1e-6
+        tol = 2e-2 if n.endswith("bias") else 1e-2
+        np.testing.assert_allclose(got[n].cpu().numpy() / scale, ref[n].cpu().numpy() / scale, atol=tol, err_msg=n)
+        n_bias += n.endswith("dense.bias") or n.endswith("query.bias")
+    assert n_bias >= 8
