@@ -35,6 +35,7 @@ for p in (ROOT, os.path.join(ROOT, "gloria-nlp-project_amd")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
+os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")   # before the HIP runtime starts: gloria/hipgraph.py
 torch = None                    # imported by main() AFTER the launcher decision: the parent of a multi-rank run stays off the GPU
 
 GLOBAL_BATCH = 256
@@ -409,6 +410,7 @@ def main():
                        "world_size_seen": torch.distributed.get_world_size() if dctx else 1,
                        "encoder_streams": 2 if GM.ENCODER_STREAMS else 1,
                        "image_encoder_hipgraph": bool(model.gloria._img_graph is not None),
+                       "text_encoder_hipgraph": bool(getattr(model.gloria.text_encoder, "_graph", None) is not None),
                        "kernel_launches_per_step": launches, "sum_cap_lens": cap_lens_sum,
                        "parallelism": f"dp{world}" + (" (text-embedding all-gather + grad all-reduce, RCCL)" if world > 1 else ""),
                        "final_loss": float(loss)},

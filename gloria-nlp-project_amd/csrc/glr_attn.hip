@@ -36,6 +36,7 @@ struct AttnParams {
   int B, nh, L, ld, ld_o;           // row strides (elements) of q / k / v / dq / dk / dv and of o / d_o
   float scale, p_drop;
   unsigned seed_lo, seed_hi, off_lo, off_hi;
+  const unsigned long long* rng;   // NULL, or device cell {seed, offset base}: key = (rng[0], rng[1] + offset) (hipGraph replays)
   unsigned short* o;                // fwd out / bwd in
   float* lse;                       // [B * nh, 128]
   unsigned* keep;                   // [B * nh, 128, 4] keep bits: key 32 j + i of query row r = bit i of word (r, j)
@@ -201,7 +202,12 @@ __global__ void __launch_bounds__(AT_NT) k_attn_fwd(AttnParams p) {
   const float sl = p.scale * AT_LOG2E;
   unsigned char* slab = Ps + wave * 32 * AT_SP;
   unsigned mw0 = 0u, mw1 = 0u;
-  const unsigned hk0 = p.seed_lo ^ (p.off_lo * 0x9E3779B9u), hk1 = p.seed_hi ^ (p.off_hi * 0x85EBCA6Bu) ^ 0xC2B2AE35u;
+  unsigned sd_lo = p.seed_lo, sd_hi = p.seed_hi, of_lo = p.off_lo, of_hi = p.off_hi;
+  if (p.rng != nullptr) {
+    const unsigned long long s = p.rng[0], o = p.rng[1] + (((unsigned long long)p.off_hi << 32) | p.off_lo);
+    sd_lo = (unsigned)s; sd_hi = (unsigned)(s >> 32); of_lo = (unsigned)o; of_hi = (unsigned)(o >> 32);
+  }
+  const unsigned hk0 = sd_lo ^ (of_lo * 0x9E3779B9u), hk1 = sd_hi ^ (of_hi * 0x85EBCA6Bu) ^ 0xC2B2AE35u;
 #pragma unroll
   for (int q = 0; q < 16; ++q) {
     const int r = acc_row(q, h);
@@ -449,6 +455,7 @@ int attn_fill(AttnParams& p, const void* q, const void* k, const void* v, const 
   p.q = (const unsigned short*)q; p.k = (const unsigned short*)k; p.v = (const unsigned short*)v; p.key_mask = key_mask;
   p.B = B; p.nh = nh; p.L = L; p.ld = ld; p.ld_o = ld_o; p.scale = scale; p.p_drop = p_drop;
   p.seed_lo = (unsigned)seed; p.seed_hi = (unsigned)(seed >> 32); p.off_lo = (unsigned)offset; p.off_hi = (unsigned)(offset >> 32);
+  p.rng = nullptr;
   p.o = nullptr; p.lse = nullptr; p.keep = nullptr; p.d_o = nullptr; p.dq = p.dk = p.dv = nullptr;
   p.tp = attn_tp(L);
   return GLR_OK;
@@ -463,13 +470,13 @@ extern "C" int glr_attn_max_tokens(int backward) {
 }
 
 extern "C" int glr_attn_fwd(const void* q, const void* k, const void* v, const uint8_t* key_mask, int B, int n_heads, int L, int ld,
-                            int ld_o, float scale, float p_drop, unsigned long long seed, unsigned long long offset, void* o, float* lse,
-                            uint32_t* keep, void* stream) {
+                            int ld_o, float scale, float p_drop, unsigned long long seed, unsigned long long offset,
+                            const unsigned long long* rng_cell, void* o, float* lse, uint32_t* keep, void* stream) {
   AttnParams p;
   const int rc = attn_fill(p, q, k, v, key_mask, B, n_heads, L, ld, ld_o, scale, p_drop, seed, offset);
   if (rc != GLR_OK) return rc;
   if (!o || !lse || (p_drop > 0.f && !keep) || L > glr_attn_max_tokens(0)) return GLR_EINVAL;
-  p.o = (unsigned short*)o; p.lse = lse; p.keep = keep;
+  p.o = (unsigned short*)o; p.lse = lse; p.keep = keep; p.rng = rng_cell;
   const int lds = (int)attn_lds_fwd(L);
   static GlrLdsAttr lds_fwd;
   if (glr_ensure_lds(lds_fwd, (const void*)k_attn_fwd, lds) != GLR_OK) return GLR_ELAUNCH;

@@ -48,12 +48,17 @@ template <int NQ>
 __global__ void __launch_bounds__(LN_NT) k_drop_add_ln_fwd(const unsigned short* __restrict__ h, const float* __restrict__ inp,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
                                                            long long R, float eps, float p_drop, unsigned seed_lo, unsigned seed_hi,
-                                                           unsigned off_lo, unsigned off_hi, float* __restrict__ out32, unsigned short* __restrict__ out16,
+                                                           unsigned off_lo, unsigned off_hi, const unsigned long long* __restrict__ rng,
+                                                           float* __restrict__ out32, unsigned short* __restrict__ out16,
                                                            float* __restrict__ stats, unsigned long long* __restrict__ mask) {
   constexpr int H = NQ * 256;
   const int lane = threadIdx.x & 63;
   const long long row = (long long)blockIdx.x * (LN_NT / 64) + (threadIdx.x >> 6);
   if (row >= R) return;
+  if (rng != nullptr) {        // key from device memory (hipGraph replays: the host rewrites the cell before each replay)
+    const unsigned long long s = rng[0], o = rng[1] + (((unsigned long long)off_hi << 32) | off_lo);
+    seed_lo = (unsigned)s; seed_hi = (unsigned)(s >> 32); off_lo = (unsigned)o; off_hi = (unsigned)(o >> 32);
+  }
   const bool drop = p_drop > 0.f;
   const unsigned thr = drop ? (unsigned)fminf(p_drop * 4294967296.f, 4294967040.f) : 0u;
   const float inv_keep = drop ? 1.f / (1.f - p_drop) : 1.f;
@@ -324,15 +329,16 @@ extern "C" int glr_colsum_bf16(const void* x16, long long R, int C, float* works
 }
 
 extern "C" int glr_drop_add_ln_fwd(const void* h16, const float* inp32, const float* gamma, const float* beta, long long R, int H,
-                                   float eps, float p_drop, unsigned long long seed, unsigned long long offset, float* out32,
-                                   void* out16, float* stats, unsigned long long* mask, void* stream) {
+                                   float eps, float p_drop, unsigned long long seed, unsigned long long offset,
+                                   const unsigned long long* rng_cell, float* out32, void* out16, float* stats,
+                                   unsigned long long* mask, void* stream) {
   if (!h16 || !inp32 || !gamma || !beta || !out32 || !out16 || !stats || !ln_shape_ok(R, H)) return GLR_EINVAL;
   if (p_drop < 0.f || p_drop >= 1.f || (p_drop > 0.f && !mask)) return GLR_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   const int grid = (int)((R + LN_NT / 64 - 1) / (LN_NT / 64));
 #define GLR_LN_FWD(NQ)                                                                                                      \
   hipLaunchKernelGGL((k_drop_add_ln_fwd<NQ>), dim3(grid), dim3(LN_NT), 0, st, (const unsigned short*)h16, inp32, gamma, beta, R, \
-                     eps, p_drop, (unsigned)seed, (unsigned)(seed >> 32), (unsigned)offset, (unsigned)(offset >> 32), out32, (unsigned short*)out16, stats, mask)
+                     eps, p_drop, (unsigned)seed, (unsigned)(seed >> 32), (unsigned)offset, (unsigned)(offset >> 32), rng_cell, out32, (unsigned short*)out16, stats, mask)
   switch (H / 256) {
     case 1: GLR_LN_FWD(1); break;
     case 2: GLR_LN_FWD(2); break;

@@ -60,14 +60,15 @@ SYMBOLS = {
                                c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "glr_ln_workspace_floats": (c_int, [ctypes.c_longlong, c_int]),
     "glr_drop_add_ln_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_longlong, c_int, c_float, c_float,
-                                    ctypes.c_ulonglong, ctypes.c_ulonglong, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+                                    ctypes.c_ulonglong, ctypes.c_ulonglong, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                    c_void_p]),
     "glr_drop_add_ln_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_longlong,
                                     c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "glr_colsum_workspace_floats": (c_int, [ctypes.c_longlong, c_int]),
     "glr_colsum_bf16": (c_int, [c_void_p, ctypes.c_longlong, c_int, c_void_p, c_void_p, c_int, c_void_p]),
     "glr_attn_max_tokens": (c_int, [c_int]),
     "glr_attn_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_float,
-                             ctypes.c_ulonglong, ctypes.c_ulonglong, c_void_p, c_void_p, c_void_p, c_void_p]),
+                             ctypes.c_ulonglong, ctypes.c_ulonglong, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "glr_attn_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
                              c_int, c_int, c_int, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
     "glr_upsample_bilinear_cl": (c_int, [c_void_p, ctypes.c_longlong, ctypes.c_longlong, ctypes.c_longlong, ctypes.c_longlong,

@@ -130,6 +130,24 @@ class BertEncoderStack(nn.Module):
         self.layer = nn.ModuleList([BertLayer(c) for _ in range(c.num_hidden_layers)])
 
 
+class BertStackPath(nn.Module):
+    """The encoder layers as an (embedding output, key mask) -> (last n hidden states) module of tensors only: the
+    callable BertEncoder.enable_graph hands to torch.cuda.make_graphed_callables.  The embeddings stay outside (their
+    backward sorts the token ids: launch shapes that depend on the data), and so does the pooler (unused parameters)."""
+
+    def __init__(self, encoder, n_out):
+        super().__init__()
+        self.encoder = encoder
+        self.n_out = int(n_out)
+
+    def forward(self, x, key_mask4):
+        hidden, x16 = [], None
+        for layer in self.encoder.layer:
+            x, x16 = layer(x, key_mask4, x16)
+            hidden.append(x)
+        return tuple(hidden[-self.n_out:])
+
+
 class BertPooler(nn.Module):
     def __init__(self, c):
         super().__init__()

@@ -19,7 +19,7 @@ import torch
 import torch.nn.functional as F
 
 from .. import _native as N
-from .fused_ln import _philox_args
+from .rng import philox_args
 
 ENABLED = os.environ.get("GLR_FUSED_ATTN", "1") != "0"
 _MAX_L = None
@@ -41,9 +41,9 @@ class _SelfAttn(torch.autograd.Function):
         o = torch.empty_like(q)
         lse = torch.empty(B * nh, 128, dtype=torch.float32, device=dev)
         keep = torch.empty(B * nh, 128, 4, dtype=torch.int32, device=dev) if p > 0 else None
-        seed, off = _philox_args(dev) if p > 0 else (0, 0)
+        seed, off, cell = philox_args(dev) if p > 0 else (0, 0, None)
         N.check(L_.glr_attn_fwd(N.ptr(q), N.ptr(k), N.ptr(v), N.ptr(key_mask), B, nh, L, H, H, float(scale), float(p), seed, off,
-                                N.ptr(o), N.ptr(lse), N.ptr(keep), N.stream()), "glr_attn_fwd")
+                                cell, N.ptr(o), N.ptr(lse), N.ptr(keep), N.stream()), "glr_attn_fwd")
         ctx.save_for_backward(q, k, v, o, lse, keep, key_mask)
         ctx.meta = (nh, float(p), float(scale))
         return o
@@ -74,10 +74,10 @@ class _SelfAttnPacked(torch.autograd.Function):
         o = torch.empty(B, L, H, dtype=qkv.dtype, device=dev)
         lse = torch.empty(B * nh, 128, dtype=torch.float32, device=dev)
         keep = torch.empty(B * nh, 128, 4, dtype=torch.int32, device=dev) if p > 0 else None
-        seed, off = _philox_args(dev) if p > 0 else (0, 0)
+        seed, off, cell = philox_args(dev) if p > 0 else (0, 0, None)
         base = qkv.data_ptr()
         N.check(L_.glr_attn_fwd(N.c_void_p(base), N.c_void_p(base + 2 * H), N.c_void_p(base + 4 * H), N.ptr(key_mask), B, nh, L, H3, H,
-                                float(scale), float(p), seed, off, N.ptr(o), N.ptr(lse), N.ptr(keep), N.stream()),
+                                float(scale), float(p), seed, off, cell, N.ptr(o), N.ptr(lse), N.ptr(keep), N.stream()),
                 "glr_attn_fwd")
         ctx.save_for_backward(qkv, o, lse, keep, key_mask)
         ctx.meta = (nh, float(p), float(scale))

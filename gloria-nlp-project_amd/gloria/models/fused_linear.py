@@ -30,6 +30,8 @@ def _workspace(dev, R, C):
         n = _WS_FLOATS[(R, C)] = int(N.lib().glr_colsum_workspace_floats(R, C))
     if n == 0:
         return None
+    if torch.cuda.is_current_stream_capturing():        # a graph keeps its own: the shared one may be replaced later
+        return torch.empty(n, dtype=torch.float32, device=dev)
     key = (dev.index, N.stream())
     ws = _WS.get(key)
     if ws is None or ws.numel() < n:

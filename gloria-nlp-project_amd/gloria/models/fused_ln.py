@@ -17,6 +17,7 @@ import torch
 import torch.nn.functional as F
 
 from .. import _native as N
+from .rng import philox_args
 
 ENABLED = os.environ.get("GLR_FUSED_LN", "1") != "0"
 _WS = {}            # (device index, stream) -> fp32 workspace: launches of one stream only (see fused_bn)
@@ -29,19 +30,14 @@ def _workspace(dev, R, H):
     n = _WS_FLOATS.get((R, H))
     if n is None:
         n = _WS_FLOATS[(R, H)] = int(N.lib().glr_ln_workspace_floats(R, H))
+    if torch.cuda.is_current_stream_capturing():        # a graph keeps its own: the shared one may be replaced later
+        return torch.empty(n, dtype=torch.float32, device=dev)
     key = (dev.index, N.stream())
     ws = _WS.get(key)
     if ws is None or ws.numel() < n:
         ws = torch.empty(max(n, 1 << 21), dtype=torch.float32, device=dev)
         _WS[key] = ws
     return ws
-
-
-def _philox_args(dev):
-    gen = torch.cuda.default_generators[dev.index if dev.index is not None else torch.cuda.current_device()]
-    seed, off = gen.initial_seed(), gen.get_offset()
-    gen.set_offset(off + 4)
-    return seed & 0xFFFFFFFFFFFFFFFF, off
 
 
 class _DropAddLN(torch.autograd.Function):
@@ -57,9 +53,9 @@ class _DropAddLN(torch.autograd.Function):
         out16 = torch.empty(h.shape, dtype=torch.bfloat16, device=dev)
         stats = torch.empty(R, 2, dtype=torch.float32, device=dev)
         mask = torch.empty(R, H // 64, dtype=torch.int64, device=dev) if p > 0 else None
-        seed, off = _philox_args(dev) if p > 0 else (0, 0)
+        seed, off, cell = philox_args(dev) if p > 0 else (0, 0, None)
         N.check(L.glr_drop_add_ln_fwd(N.ptr(h), N.ptr(inp), N.ptr(weight), N.ptr(bias), R, H, float(eps), float(p), seed, off,
-                                      N.ptr(out32), N.ptr(out16), N.ptr(stats), N.ptr(mask), N.stream()), "glr_drop_add_ln_fwd")
+                                      cell, N.ptr(out32), N.ptr(out16), N.ptr(stats), N.ptr(mask), N.stream()), "glr_drop_add_ln_fwd")
         ctx.save_for_backward(h, inp, weight, stats, mask)
         ctx.p = float(p)
         ctx.hb = None if h_bias is None else (h_bias.dtype, h_bias.shape)

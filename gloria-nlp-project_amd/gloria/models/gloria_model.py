@@ -119,21 +119,35 @@ class GLoRIA(nn.Module):
         embedding backward replays with capture-time sizes (round 1's aperture violation), and its dropout keys come
         from the host.  BatchNorm buffers are restored after the warm-up passes, so the first real step sees the
         statistics an eager run would."""
+        from .. import hipgraph
         if not sample_imgs.is_cuda or self.position_embeddings is not None or self.image_transformer is not None:
+            return False
+        if not hipgraph.usable("image encoder"):
             return False
         path = _ImagePath(self.img_encoder)
         path.train(self.training)
         keep = {k: v.detach().clone() for k, v in self.img_encoder.named_buffers()}
         ctx = torch.autocast("cuda", dtype=autocast_dtype, cache_enabled=False) if autocast_dtype is not None \
             else torch.autocast("cuda", enabled=False)
+        sample = (sample_imgs.detach().clone(),)
         with ctx:
-            graphed = torch.cuda.make_graphed_callables(path, (sample_imgs.detach().clone(),), num_warmup_iters=warmup)
+            graphed = torch.cuda.make_graphed_callables(path, sample, num_warmup_iters=warmup)
+            # replays against an eager pass before the graph is trusted (gloria/hipgraph.py: memset nodes race on this stack)
+            ok = hipgraph.verify_capture("image encoder", path, graphed, sample)
         with torch.no_grad():
             for k, v in self.img_encoder.named_buffers():
                 v.copy_(keep[k])
+        if not ok:
+            return False
         object.__setattr__(self, "_img_graph", graphed)
         self._img_graph_shape = (tuple(sample_imgs.shape), sample_imgs.dtype)
         return True
+
+    def enable_text_graph(self, caption_ids, attention_mask, token_type_ids, autocast_dtype=None, warmup=3):
+        """hipGraph capture of the text encoder's layers, forward and backward (text_model.BertEncoder.enable_graph)"""
+        if not hasattr(self.text_encoder, "enable_graph"):
+            return False
+        return self.text_encoder.enable_graph(caption_ids, attention_mask, token_type_ids, autocast_dtype, warmup)
 
     def image_encoder_forward(self, imgs):
         if (self._img_graph is not None and self.training and torch.is_grad_enabled()

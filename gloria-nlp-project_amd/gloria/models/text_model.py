@@ -199,11 +199,56 @@ class BertEncoder(nn.Module):
             self.vocab = Vocab.synthetic(bcfg.vocab_size)
         self.idxtoword = None          # built on demand (reference attribute, text_model.py:23)
 
+        # set by enable_graph(); out of the module tree (the graphed callable wraps self.model.encoder)
+        object.__setattr__(self, "_graph", None)
+        self._graph_key = None
+        self._graph_rng = None
+
         self.emb_global, self.emb_local = None, None
         if self.freeze_bert is True:
             print("Freezing BERT model")
             for param in self.model.parameters():
                 param.requires_grad = False
+
+    def enable_graph(self, ids, attn_mask, token_type, autocast_dtype=None, warmup=3):
+        """Capture the encoder layers' forward AND backward (12 layers: ~600 of the step's launches, static shapes) into
+        two hipGraphs (torch.cuda.make_graphed_callables on bert.BertStackPath).  Small per-rank batches are bound by the
+        HOST time of exactly these launches.  Dropout keys of the fused kernels come from a device cell rewritten before
+        every replay (models/rng.py), so a replay draws fresh masks from torch's generator like the eager launches."""
+        from .. import hipgraph
+        from .bert import BertStackPath
+        from .rng import GraphRng, capturing
+        n_layers = len(self.model.encoder.layer)
+        if (not ids.is_cuda or attn_mask is None or self.freeze_bert is True or self.last_n_layers <= 1
+                or self.last_n_layers > n_layers or not hipgraph.usable("text encoder")):
+            return False
+        path = BertStackPath(self.model.encoder, self.last_n_layers)
+        path.train(self.training)
+        ctx = torch.autocast("cuda", dtype=autocast_dtype, cache_enabled=False) if autocast_dtype is not None \
+            else torch.autocast("cuda", enabled=False)
+        rng = GraphRng(ids.device)
+        with ctx:
+            with torch.no_grad():
+                x = self.model.embeddings(ids, token_type)
+            x = x.detach().clone().requires_grad_(True)
+            mask4 = (attn_mask != 0)[:, None, None, :].clone()
+            with capturing(rng):
+                graphed = torch.cuda.make_graphed_callables(path, (x, mask4), num_warmup_iters=warmup)
+            if not hipgraph.verify_capture("text encoder", path, graphed, (x, mask4), before_replay=rng.refresh):
+                return False
+        object.__setattr__(self, "_graph", graphed)
+        self._graph_key = (tuple(ids.shape), autocast_dtype)
+        self._graph_rng = rng
+        return True
+
+    def _encode(self, ids, attn_mask, token_type):
+        """hidden states of the last `last_n_layers` layers, through the captured graphs when they fit this call"""
+        if (self._graph is not None and self.training and torch.is_grad_enabled() and attn_mask is not None
+                and self._graph_key == (tuple(ids.shape), torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else None)):
+            x = self.model.embeddings(ids, token_type)
+            self._graph_rng.refresh()
+            return self._graph(x, (attn_mask != 0)[:, None, None, :])
+        return None
 
     def aggregate_tokens(self, embeddings, caption_ids):
         """embeddings [B, L, D] (already reduced over layers) -> word slots [B, L, D], sents."""
@@ -219,10 +264,12 @@ class BertEncoder(nn.Module):
         return out.view(B, L, -1), sents
 
     def forward(self, ids, attn_mask, token_type):
-        outputs = self.model(ids, attn_mask, token_type)
+        layers = self._encode(ids, attn_mask, token_type) if self.last_n_layers > 1 else None
+        outputs = self.model(ids, attn_mask, token_type) if layers is None else None
         fused = None
         if self.last_n_layers > 1:
-            layers = outputs[2][-self.last_n_layers:]
+            if layers is None:
+                layers = outputs[2][-self.last_n_layers:]
             if self.aggregate_method not in ("sum", "mean"):
                 print(self.aggregate_method)
                 raise Exception("Aggregation method not implemented")

@@ -13,7 +13,7 @@ import torch
 
 class Trainer:
     def __init__(self, cfg, device="cuda", precision=None, dist_ctx=None, log_path=None, miopen_benchmark=False,
-                 sync_bn=False, flat_optimizer=None, graph_image_encoder=None):
+                 sync_bn=False, flat_optimizer=None, graph_image_encoder=None, graph_text_encoder=None):
         self.cfg = cfg
         self.device = torch.device(device)
         prec = precision if precision is not None else cfg.lightning.trainer.precision
@@ -31,13 +31,17 @@ class Trainer:
         # per-channel all-reduce per layer) - the reference oracle is single-device full-batch BN (SURVEY.md
         # section 7); the default keeps per-rank statistics (speed mode)
         self.sync_bn = bool(sync_bn)
-        # hipGraph capture of the image encoder's forward + backward at the first training step (GLoRIA.enable_image_graph):
-        # 81.1 -> 79.7 ms per step at 256 pairs, 20.5 -> 18.5 ms at 32 (single process); on the data-parallel path at 32
-        # pairs per rank 27.7 -> 20.3 ms with the hook-driven reducer and 16.1 ms with the hook-free one (below).  Off
-        # with SyncBatchNorm (a collective inside the capture).  GLR_GRAPH_IMG=0/1 overrides.
-        if graph_image_encoder is None:
-            graph_image_encoder = os.environ.get("GLR_GRAPH_IMG", "1") != "0"
-        self.graph_image_encoder = bool(graph_image_encoder) and not self.sync_bn
+        # hipGraph capture of both encoders' forward + backward at the first training step (GLoRIA.enable_image_graph: the
+        # whole image encoder; BertEncoder.enable_graph: the 12 BERT layers): small per-rank batches are bound by the HOST
+        # time of ~1100 launches.  Measured with the graph-safe runtime flag of gloria/hipgraph.py, data-parallel path on
+        # one GPU (single-rank RCCL), ms per step: 32 pairs 25.3 eager -> 17.9 image graph -> 16.0 both; 64: 24.8; 128: 42.3;
+        # at 256 pairs the GPU is the limit and the replays cost 1.4 ms (78.6 vs 77.3 eager).  Default (None): captured
+        # when the per-rank batch is <= GRAPH_MAX_BATCH; GLR_GRAPH_IMG / GLR_GRAPH_TXT = 0 / 1 override.  The image graph
+        # is off with SyncBatchNorm (a collective inside the capture), the text graph needs the flat bf16 optimizer.
+        self.graph_image_encoder = self._tristate(graph_image_encoder, "GLR_GRAPH_IMG")
+        self.graph_text_encoder = self._tristate(graph_text_encoder, "GLR_GRAPH_TXT")
+        if self.sync_bn:
+            self.graph_image_encoder = False
         self._graph_tried = False
         # bucketed all-reduce overlapped with backward (hooks) or one gather + all-reduce per group after it
         # (GradReducer.from_flat); GLR_REDUCER_OVERLAP=0/1 overrides the default
@@ -54,6 +58,15 @@ class Trainer:
             flat_optimizer = os.environ.get("GLR_FLAT_OPTIMIZER", "1") != "0"
         self.flat_optimizer = bool(flat_optimizer) and self.device.type == "cuda" and self.autocast_dtype is not None \
             and cfg.train.optimizer.name == "Adam"
+
+    GRAPH_MAX_BATCH = 128
+
+    @staticmethod
+    def _tristate(arg, env):
+        if arg is not None:
+            return bool(arg)
+        v = os.environ.get(env)
+        return None if v is None else v != "0"
 
     # ------------------------------------------------------------------ setup
     def setup(self, model):
@@ -104,9 +117,14 @@ class Trainer:
     # ------------------------------------------------------------------ one optimisation step
     def training_step(self, model, batch, batch_idx=0):
         batch = self.to_device(batch)
-        if self.graph_image_encoder and not self._graph_tried and self.device.type == "cuda" and self.autocast_dtype is not None:
+        if not self._graph_tried and self.device.type == "cuda" and self.autocast_dtype is not None:
             self._graph_tried = True          # once: the batch shape is static in training (drop_last loaders)
-            model.gloria.enable_image_graph(batch["imgs"], self.autocast_dtype)
+            auto = int(batch["imgs"].shape[0]) <= self.GRAPH_MAX_BATCH
+            if auto if self.graph_image_encoder is None else self.graph_image_encoder:
+                model.gloria.enable_image_graph(batch["imgs"], self.autocast_dtype)
+            if (auto if self.graph_text_encoder is None else self.graph_text_encoder) and self.flat_optimizer:
+                model.gloria.enable_text_graph(batch["caption_ids"], batch["attention_mask"], batch["token_type_ids"],
+                                               self.autocast_dtype)
         ctx = torch.autocast(self.device.type, dtype=self.autocast_dtype) if self.autocast_dtype else _Null()
         with ctx:
             out = model.training_step(batch, batch_idx)
@@ -116,7 +134,7 @@ class Trainer:
             loss.backward()                   # bucket all-reduces start as soon as a bucket is complete
             self.reducer.finish()
         else:
-            self.optimizer.zero_grad(set_to_none=not self.flat)
+            self.optimizer.zero_grad(set_to_none=True)
             loss.backward()
         if self.clip and not self.flat:       # the flat optimizer clips inside its step (post-reduce global norm)
             torch.nn.utils.clip_grad_norm_(self.params, self.clip)

@@ -384,6 +384,7 @@ int glr_bn_act_bwd(const void* x, const void* dy, const void* dy2, const void* y
  *   stats  fp32 [R, 2]  mean, 1/std per row (for the backward)        mask   u64 [R, H/64] dropout keep bits: element
  *                       4 (l + 64 i) + c of a row is bit l of word 4 i + c  (NULL when p_drop == 0)
  *   seed / offset       Philox4x32-10 key / counter prefix: the mask is a pure function of (seed, offset, row, column)
+ *   rng_cell            NULL, or device memory {seed, offset base}: key = (cell[0], cell[1] + offset) (hipGraph replays)
  * bwd: dy32 / dy16 = gradients w.r.t. out32 / out16 (either may be NULL); d_inp32 fp32, d_h16 bf16, dgamma / dbeta fp32 [H];
  *      dhsum (NULL = not wanted): column sums of d_h, fp32 or bf16 [H] (dhsum_bf16) - the bias gradient of the dense
  *      Linear that produced h;  workspace: glr_ln_workspace_floats(R, H) floats (0 = shape not supported).
@@ -395,8 +396,9 @@ int glr_bn_act_bwd(const void* x, const void* dy, const void* dy2, const void* y
  */
 int glr_ln_workspace_floats(long long R, int H);
 int glr_drop_add_ln_fwd(const void* h16, const float* inp32, const float* gamma, const float* beta, long long R, int H,
-                        float eps, float p_drop, unsigned long long seed, unsigned long long offset, float* out32,
-                        void* out16, float* stats, unsigned long long* mask, void* stream);
+                        float eps, float p_drop, unsigned long long seed, unsigned long long offset,
+                        const unsigned long long* rng_cell, float* out32, void* out16, float* stats, unsigned long long* mask,
+                        void* stream);
 int glr_drop_add_ln_bwd(const float* dy32, const void* dy16, const void* h16, const float* inp32, const float* gamma,
                         const float* stats, const unsigned long long* mask, long long R, int H, float p_drop,
                         float* d_inp32, void* d_h16, float* workspace, float* dgamma, float* dbeta, void* dhsum, int dhsum_bf16,
@@ -412,14 +414,16 @@ int glr_colsum_bf16(const void* x16, long long R, int C, float* workspace, void*
  * Linear outputs read in place: ld = hidden size for three Linears, 3 x hidden for one fused query|key|value Linear whose
  * three column blocks are passed as q, k, v); key_mask uint8 [B, L] (nonzero = attend) or NULL; lse fp32 [B * n_heads, 128] (row
  * log-sum-exp, saved for the backward); keep uint32 [B * n_heads, 128, 4]: dropout keep bits, key 32 j + i of query
- * row r = bit i of word (r, j) (NULL when p_drop == 0).  seed / offset: Philox4x32-10 key / counter prefix.
+ * row r = bit i of word (r, j) (NULL when p_drop == 0).  seed / offset: key of the counter hash that draws the bits;
+ * rng_cell (NULL = not used): device memory {seed, offset base} read by the kernel, key = (cell[0], cell[1] + offset) -
+ * launches captured in a hipGraph get fresh bits per replay by rewriting the cell (gloria/models/rng.py).
  * One workgroup per (sentence, head) and pass (the backward runs a query pass and a key pass); glr_attn_max_tokens(
  * backward) = largest supported L (128).  Replaces a library flash-attention call that spends 95 + 390 us per layer here.
  */
 int glr_attn_max_tokens(int backward);
 int glr_attn_fwd(const void* q, const void* k, const void* v, const uint8_t* key_mask, int B, int n_heads, int L, int ld,
-                 int ld_o, float scale, float p_drop, unsigned long long seed, unsigned long long offset, void* o, float* lse,
-                 uint32_t* keep, void* stream);
+                 int ld_o, float scale, float p_drop, unsigned long long seed, unsigned long long offset,
+                 const unsigned long long* rng_cell, void* o, float* lse, uint32_t* keep, void* stream);
 int glr_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o, const uint8_t* key_mask,
                  const float* lse, const uint32_t* keep, int B, int n_heads, int L, int ld, int ld_o, float scale, float p_drop,
                  void* dq, void* dk, void* dv, void* stream);

@@ -4,6 +4,7 @@ import sys
 import numpy as np
 import pytest
 
+os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")   # before the HIP runtime starts: gloria/hipgraph.py
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "gloria-nlp-project_amd"), os.path.join(ROOT, "tests")):
     if p not in sys.path:

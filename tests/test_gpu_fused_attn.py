@@ -48,8 +48,14 @@ def test_attention_matches_torch(B, nh, L, p, ragged):
     lse = torch.empty(B * nh, 128, device=DEV)
     keep = torch.zeros(B * nh, 128, 4, dtype=torch.int32, device=DEV) if p > 0 else None
     scale = 1.0 / math.sqrt(64)
-    N.check(Lb.glr_attn_fwd(N.ptr(q), N.ptr(k), N.ptr(v), N.ptr(key_mask), B, nh, L, H, H, scale, p, 99, 4, N.ptr(o), N.ptr(lse),
+    N.check(Lb.glr_attn_fwd(N.ptr(q), N.ptr(k), N.ptr(v), N.ptr(key_mask), B, nh, L, H, H, scale, p, 99, 4, None, N.ptr(o), N.ptr(lse),
                             N.ptr(keep), N.stream()), "fwd")
+    if p > 0:          # the key read from a device cell {seed, offset base}: the same bits
+        cell = torch.tensor([99, 0], dtype=torch.int64, device=DEV)
+        o2, keep2 = torch.empty_like(q), torch.zeros_like(keep)
+        N.check(Lb.glr_attn_fwd(N.ptr(q), N.ptr(k), N.ptr(v), N.ptr(key_mask), B, nh, L, H, H, scale, p, 0, 4, N.ptr(cell), N.ptr(o2),
+                                N.ptr(lse), N.ptr(keep2), N.stream()), "fwd cell")
+        assert torch.equal(keep, keep2) and torch.equal(o, o2)
     km = None
     if p > 0:
         km = _decode_keep(keep, B, nh, L).to(DEV)

@@ -38,7 +38,7 @@ def test_drop_add_ln_matches_torch(R, H, p):
     out16 = torch.empty(R, H, device=DEV, dtype=torch.bfloat16)
     stats = torch.empty(R, 2, device=DEV)
     mask = torch.zeros(R, H // 64, dtype=torch.int64, device=DEV) if p > 0 else None
-    N.check(L.glr_drop_add_ln_fwd(N.ptr(h), N.ptr(inp), N.ptr(w), N.ptr(b), R, H, 1e-12, p, 1234, 8, N.ptr(out32), N.ptr(out16),
+    N.check(L.glr_drop_add_ln_fwd(N.ptr(h), N.ptr(inp), N.ptr(w), N.ptr(b), R, H, 1e-12, p, 1234, 8, None, N.ptr(out32), N.ptr(out16),
                                   N.ptr(stats), N.ptr(mask), N.stream()), "fwd")
     keep = _decode_mask(mask, R, H).to(DEV) if p > 0 else torch.ones(R, H, dtype=torch.bool, device=DEV)
     if p > 0:
@@ -89,10 +89,10 @@ def test_dropout_mask_is_a_function_of_seed_and_offset():
     inp = torch.randn(R, H, device=DEV)
     w, b = torch.ones(H, device=DEV), torch.zeros(H, device=DEV)
 
-    def run(seed, off):
+    def run(seed, off, cell=None):
         o32 = torch.empty(R, H, device=DEV); o16 = torch.empty(R, H, device=DEV, dtype=torch.bfloat16)
         st = torch.empty(R, 2, device=DEV); m = torch.zeros(R, H // 64, dtype=torch.int64, device=DEV)
-        N.check(L.glr_drop_add_ln_fwd(N.ptr(h), N.ptr(inp), N.ptr(w), N.ptr(b), R, H, 1e-12, 0.1, seed, off, N.ptr(o32), N.ptr(o16),
+        N.check(L.glr_drop_add_ln_fwd(N.ptr(h), N.ptr(inp), N.ptr(w), N.ptr(b), R, H, 1e-12, 0.1, seed, off, N.ptr(cell), N.ptr(o32), N.ptr(o16),
                                       N.ptr(st), N.ptr(m), N.stream()), "fwd")
         return o32, m
     a, ma = run(7, 0)
@@ -101,6 +101,14 @@ def test_dropout_mask_is_a_function_of_seed_and_offset():
     _, mc = run(7, 4)
     _, md = run(8, 0)
     assert not torch.equal(ma, mc) and not torch.equal(ma, md)
+    # key from a device cell {seed, offset base} (+ the site offset passed by value): the same masks
+    cell = torch.tensor([7, 0], dtype=torch.int64, device=DEV)
+    _, me = run(123, 0, cell)
+    cell.copy_(torch.tensor([7, 4], dtype=torch.int64))
+    _, mf = run(0, 0, cell)
+    cell.copy_(torch.tensor([7, 0], dtype=torch.int64))
+    _, mg = run(0, 4, cell)
+    assert torch.equal(me, ma) and torch.equal(mf, mc) and torch.equal(mg, mc)
 
 
 def test_bert_fused_sublayers_match_unfused_under_autocast(monkeypatch):

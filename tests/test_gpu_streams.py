@@ -5,6 +5,7 @@ data-parallel path (bucketed reducer, here on a single-rank RCCL group).  Nothin
 the dropout keys are drawn on the host in program order, so the only differences allowed are those of the library GEMMs /
 convolutions, which are not bitwise reproducible between two runs (split reductions): bf16-level bands, stated below."""
 
+import os
 import socket
 
 import numpy as np
@@ -129,7 +130,7 @@ def test_graphed_image_encoder_equals_eager():
         cfg = pretrain_config("imagenome", batch_size=B)
         torch.manual_seed(31)
         model = builder.build_lightning_model(cfg, builder.build_data_module(cfg))
-        tr = Trainer(cfg, device="cuda:0", precision="bf16", graph_image_encoder=graph)
+        tr = Trainer(cfg, device="cuda:0", precision="bf16", graph_image_encoder=graph, graph_text_encoder=False)
         tr.setup(model)
         model.train()
         batch = make_batch(B, seed=8, lengths="words")
@@ -155,6 +156,126 @@ def test_graphed_image_encoder_equals_eager():
         return loss, loss2, grads, bn
 
     _compare(run(False), run(True))
+
+
+def test_image_graph_replays_stay_correct_in_a_backward_loop():
+    """The loop that exposed the hipGraph memset race on this stack (gloria/hipgraph.py): four replays of the image
+    encoder's graphs driven by loss.backward() with the gradients released in between.  With the HIP runtime's graph
+    packet capture on, replays 1.. returned NaN / inf gradients for conv1 and layer1 (layer3 stayed right); with the flag
+    this package sets they must match the eager pass every time."""
+    from gloria import builder, hipgraph
+    from gloria.config import pretrain_config
+    from gloria.datasets.synthetic import make_batch
+    from gloria.trainer import Trainer
+    assert hipgraph.SAFE and os.environ.get(hipgraph.ENV) == "0"
+    cfg = pretrain_config("imagenome", batch_size=B)
+    torch.manual_seed(31)
+    model = builder.build_lightning_model(cfg, builder.build_data_module(cfg))
+    tr = Trainer(cfg, device="cuda:0", precision="bf16", graph_text_encoder=False)
+    tr.setup(model)
+    model.train()
+    G = model.gloria
+    imgs = tr.to_device(make_batch(B, seed=8, lengths="words"))["imgs"]
+    watch = {n: p for n, p in model.named_parameters()
+             if n.endswith(("img_encoder.model.conv1.weight", "layer1.0.conv1.weight", "layer1.2.conv3.weight", "layer2.0.conv1.weight",
+                            "layer3.0.conv1.weight", "layer4.2.conv3.weight"))}
+    assert len(watch) == 6
+
+    def one_pass():
+        for p in model.parameters():
+            p.grad = None
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            loc, glo = G.image_encoder_forward(imgs)
+            loss = loc.float().pow(2).mean() + glo.float().pow(2).mean()
+        loss.backward()
+        torch.cuda.synchronize()
+        return {n: p.grad.float().clone() for n, p in watch.items()}
+
+    keep = {k: v.detach().clone() for k, v in G.img_encoder.named_buffers()}
+    ref = one_pass()                                           # eager
+    with torch.no_grad():
+        for k, v in G.img_encoder.named_buffers():
+            v.copy_(keep[k])
+    assert G.enable_image_graph(imgs, torch.bfloat16)
+    for it in range(4):
+        got = one_pass()
+        for n in ref:
+            assert torch.isfinite(got[n]).all(), (it, n)
+            rel = float((got[n] - ref[n]).norm() / ref[n].norm())
+            # two eager passes differ by up to ~7 % here (bf16 gradients through 50 layers, split-K atomics in the
+            # weight-gradient solvers); the race gave inf / NaN / orders of magnitude
+            assert rel < 0.2, (it, n, rel)
+
+
+def test_graphed_text_encoder_equals_eager():
+    """hipGraph replay of the text encoder's 12 layers, forward + backward (BertEncoder.enable_graph), against the eager
+    path with dropout ON: the device key cell is refreshed from torch's generator exactly like the eager launches draw
+    their keys (models/rng.py), so with the same generator state both paths see the same masks and the step agrees
+    within the bands of `_compare`; a second replay must draw NEW masks."""
+    from gloria import builder
+    from gloria.config import pretrain_config
+    from gloria.datasets.synthetic import make_batch
+    from gloria.trainer import Trainer
+
+    def run(graph):
+        cfg = pretrain_config("imagenome", batch_size=B)
+        torch.manual_seed(31)
+        model = builder.build_lightning_model(cfg, builder.build_data_module(cfg))
+        tr = Trainer(cfg, device="cuda:0", precision="bf16", graph_image_encoder=False, graph_text_encoder=graph)
+        tr.setup(model)
+        model.train()
+        batch = make_batch(B, seed=8, lengths="words")
+        if graph:
+            dev_batch = tr.to_device(batch)
+            assert model.gloria.enable_text_graph(dev_batch["caption_ids"], dev_batch["attention_mask"],
+                                                  dev_batch["token_type_ids"], torch.bfloat16)
+            assert model.gloria.text_encoder._graph_rng.slots == 4 * 36          # 12 x (attention + two epilogues)
+        tr._graph_tried = True
+        torch.manual_seed(17)
+        torch.cuda.manual_seed(17)
+        loss = float(tr.training_step(model, batch, 0))
+        torch.cuda.synchronize()
+        assert (model.gloria.text_encoder._graph is not None) == bool(graph)
+        assert not any("_graph" in k for k in model.state_dict())
+        grads = {n: p.grad.float().cpu() for n, p in model.named_parameters() if p.grad is not None}
+        bn = {n: b.float().cpu().clone() for n, b in model.named_buffers() if "running_" in n}
+        loss2 = float(tr.training_step(model, batch, 1))
+        return loss, loss2, grads, bn
+
+    eager, graphed = run(False), run(True)
+    _compare(eager, graphed)
+
+
+def test_graphed_text_encoder_draws_new_masks_every_replay():
+    from gloria.models import bert as BM
+    from gloria.models import text_model as TM
+    from gloria.config import pretrain_config
+    cfg = pretrain_config("imagenome", batch_size=4)
+    torch.manual_seed(3)
+    enc = TM.BertEncoder(cfg).to("cuda:0").train()
+    for m in enc.modules():
+        if isinstance(m, torch.nn.Linear):
+            m.to(torch.bfloat16)
+    ids = torch.randint(5, 1000, (4, 97), device="cuda:0")
+    ids._glr_host = ids.cpu().numpy()
+    am = torch.ones_like(ids)
+    tt = torch.zeros_like(ids)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        assert enc.enable_graph(ids, am, tt, torch.bfloat16)
+        torch.cuda.manual_seed(5)
+        a = enc(ids, am, tt)[0].detach().float().clone()
+        b = enc(ids, am, tt)[0].detach().float().clone()
+        torch.cuda.manual_seed(5)
+        c = enc(ids, am, tt)[0].detach().float().clone()
+        # eager path, same generator state: the same masks
+        graph = enc._graph
+        object.__setattr__(enc, "_graph", None)
+        torch.cuda.manual_seed(5)
+        d = enc(ids, am, tt)[0].detach().float().clone()
+        object.__setattr__(enc, "_graph", graph)
+    assert torch.equal(a, c)                                  # same generator state -> same replay
+    assert not torch.allclose(a, b, atol=1e-3)                # next replay: fresh dropout bits
+    np.testing.assert_allclose(a.cpu().numpy(), d.cpu().numpy(), atol=3e-2, rtol=3e-2)
 
 
 def test_hook_free_reducer_equals_hook_driven_reducer(monkeypatch):
