@@ -243,7 +243,7 @@ class BertEncoder(nn.Module):
 
     def _encode(self, ids, attn_mask, token_type):
         """hidden states of the last `last_n_layers` layers, through the captured graphs when they fit this call"""
-        if (self._graph is not None and self.training and torch.is_grad_enabled() and attn_mask is not None
+        if (getattr(self, "_graph", None) is not None and self.training and torch.is_grad_enabled() and attn_mask is not None
                 and self._graph_key == (tuple(ids.shape), torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else None)):
             x = self.model.embeddings(ids, token_type)
             self._graph_rng.refresh()
