@@ -15,7 +15,14 @@
 //                    the source pixels under the crop window are read.  Every fp32 / fp64 operation is written
 //                    with explicit rounding (no FMA contraction) in the order OpenCV's scalar code performs it,
 //                    which makes the result bit-identical to the CPU restatement (oracle/collate_oracle.py).
-// The upscaling branch of cv2.INTER_AREA is not built: the host mirror rejects images whose long side is < scale.
+// Images whose long side is below `scale` are ENLARGED: cv::resize then emulates INTER_AREA with its fixed-point bilinear
+// code and area-style coordinates (mode 3 below; restated in oracle/collate_oracle.py resize_area_up_u8).
+//
+// Random transforms of builder.py:167-186 (RandomHorizontalFlip, RandomAffine, ColorJitter; torchvision 0.8.2 on PIL
+// images) as device passes over the cropped 8-bit batch with HOST-DRAWN parameters: k_collate can leave the crop as
+// uint8 [B, crop, crop]; k_aug_geom = flip + PIL's nearest-neighbour AFFINE transform (Geometry.c: the scaling special
+// case with positions accumulated in double, or 16.16 fixed point); k_img_sum + k_aug_blend = ImageEnhance brightness /
+// contrast (Blend.c, fp32, truncating); k_u8_to_tensor = ToTensor + Normalize(0.5, 0.5) on three equal channels.
 
 #include "glr_common.h"
 
@@ -241,7 +248,7 @@ template <typename T, bool MINMAX>
 __global__ __launch_bounds__(256) void k_collate(const unsigned char* __restrict__ src,
                                                  const long long* __restrict__ offset, const int* __restrict__ desc,
                                                  const unsigned* __restrict__ state, int crop,
-                                                 float* __restrict__ out) {
+                                                 float* __restrict__ out, unsigned char* __restrict__ out_u8) {
   constexpr int VEC = Src<T>::VEC;
   __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
   const int b = blockIdx.y;
@@ -267,7 +274,38 @@ __global__ __launch_bounds__(256) void k_collate(const unsigned char* __restrict
       ix = __double2int_rn(scale_x);
       iy = __double2int_rn(scale_y);
       mode = (fabs(scale_x - ix) < GLR_DBL_EPS && fabs(scale_y - iy) < GLR_DBL_EPS) ? 1 : 2;
+      if (dH > H || dW > W) mode = 3;                              // not (scale_x >= 1 && scale_y >= 1): bilinear emulation
     }
+    if (mode == 3) {
+      // cv::resize, area_mode with ksize 2 and fixed point: coefficient loop, HResizeLinear (int32), VResizeLinear 8u.
+      // Small images (long side < scale): straight from global memory.
+      if (ok) {
+        const double inv_x = div_((double)dW, (double)W), inv_y = div_((double)dH, (double)H);
+        int sx = (int)floor(mul_((double)dx, scale_x));
+        float fx = (float)sub_((double)(dx + 1), mul_((double)(sx + 1), inv_x));
+        fx = fx <= 0.f ? 0.f : sub_(fx, (float)(int)floorf(fx));
+        bool past = false;                                         // dx >= xmax: D = S[sx] * ONE
+        if (sx < 0) { fx = 0.f; sx = 0; }
+        if (sx + 1 >= W) {
+          past = true;
+          if (sx >= W - 1) { fx = 0.f; sx = W - 1; }
+        }
+        const int a0 = min(max(__float2int_rn(mul_(sub_(1.f, fx), 2048.f)), -32768), 32767);
+        const int a1 = min(max(__float2int_rn(mul_(fx, 2048.f)), -32768), 32767);
+        const int sy = (int)floor(mul_((double)dy, scale_y));
+        float fy = (float)sub_((double)(dy + 1), mul_((double)(sy + 1), inv_y));
+        fy = fy <= 0.f ? 0.f : sub_(fy, (float)(int)floorf(fy));
+        const int b0 = min(max(__float2int_rn(mul_(sub_(1.f, fy), 2048.f)), -32768), 32767);
+        const int b1 = min(max(__float2int_rn(mul_(fy, 2048.f)), -32768), 32767);
+        const int ra = min(max(sy, 0), H - 1), rb = min(max(sy + 1, 0), H - 1);
+        const int sx1 = min(sx + 1, W - 1);
+        const T* Ra = S + (long long)ra * W;
+        const T* Rb = S + (long long)rb * W;
+        const int h0 = past ? (int)q(Ra[sx]) * 2048 : (int)q(Ra[sx]) * a0 + (int)q(Ra[sx1]) * a1;
+        const int h1 = past ? (int)q(Rb[sx]) * 2048 : (int)q(Rb[sx]) * a0 + (int)q(Rb[sx1]) * a1;
+        v = ((((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2) & 255;
+      }
+    } else {
     Taps ty = {}, tx = {};
     int r0 = dy, r1 = dy + 1, c_lo = dx_lo, c_hi = dx_hi;
     if (mode == 1) {
@@ -342,8 +380,13 @@ __global__ __launch_bounds__(256) void k_collate(const unsigned char* __restrict
       }
       v = min(max(v, 0), 255);
     }
+    }
   }
   if (!active) return;
+  if (out_u8 != nullptr) {                                         // the 8-bit crop, for the transform passes
+    out_u8[((long long)b * crop + oy) * crop + ox] = (unsigned char)v;
+    return;
+  }
   const float t = div_((float)v, 255.0f);                          // ToTensor
   const float o = div_(sub_(t, 0.5f), 0.5f);                       // Normalize(0.5, 0.5)
   const long long plane = (long long)crop * crop;
@@ -353,7 +396,124 @@ __global__ __launch_bounds__(256) void k_collate(const unsigned char* __restrict
   dst[2 * plane] = o;
 }
 
+// ---- random transforms on the cropped 8-bit batch [B, n, n] (n <= 256: one thread per pixel of a row) ----
+__device__ __forceinline__ long long pil_fix(double v) {          // Geometry.c FIX: FLOOR(v * 65536.0 + 0.5)
+  const double t = add_(mul_(v, 65536.0), 0.5);
+  return t < 0.0 ? (long long)floor(t) : (long long)t;
+}
+__device__ __forceinline__ int pil_coord(double v, int n) {       // COORD: v < 0 ? -1 : (int)v  (>= n is outside anyway)
+  return v < 0.0 ? -1 : (v >= (double)n ? n : (int)v);
+}
+
+// flip[b] != 0: RandomHorizontalFlip fired; matrix[b][0..5]: PIL AFFINE coefficients (NaN in [0]: no affine).
+// out(y, x) = flipped(yin, xin) or 0 outside, flipped(y, x) = src(y, n - 1 - x).
+__global__ __launch_bounds__(256) void k_aug_geom(const unsigned char* __restrict__ src, unsigned char* __restrict__ dst, int n,
+                                                  const int* __restrict__ flip, const double* __restrict__ matrix) {
+  const int b = blockIdx.y, y = blockIdx.x, x = threadIdx.x;
+  if (x >= n) return;
+  const unsigned char* S = src + (long long)b * n * n;
+  int xi = x, yi = y;
+  const double* m = matrix ? matrix + 6 * b : nullptr;
+  if (m != nullptr && m[0] == m[0]) {
+    if (m[1] == 0.0 && m[3] == 0.0) {                               // ImagingScaleAffine: xo += a[0] per pixel, in double
+      double xo = add_(m[2], mul_(m[0], 0.5)), yo = add_(m[5], mul_(m[4], 0.5));
+      for (int i = 0; i < x; ++i) xo = add_(xo, m[0]);
+      for (int i = 0; i < y; ++i) yo = add_(yo, m[4]);
+      xi = pil_coord(xo, n);
+      yi = pil_coord(yo, n);
+    } else {                                                        // affine_fixed: 16.16 fixed point
+      const long long a0 = pil_fix(m[0]), a1 = pil_fix(m[1]), a3 = pil_fix(m[3]), a4 = pil_fix(m[4]);
+      const long long a2 = pil_fix(add_(add_(m[2], mul_(m[0], 0.5)), mul_(m[1], 0.5)));
+      const long long a5 = pil_fix(add_(add_(m[5], mul_(m[3], 0.5)), mul_(m[4], 0.5)));
+      const long long xx = (a2 + y * a1 + x * a0) >> 16, yy = (a5 + y * a4 + x * a3) >> 16;
+      xi = xx < 0 ? -1 : (xx >= n ? n : (int)xx);
+      yi = yy < 0 ? -1 : (yy >= n ? n : (int)yy);
+    }
+  }
+  unsigned char v = 0;
+  if (xi >= 0 && xi < n && yi >= 0 && yi < n) v = S[(long long)yi * n + (flip[b] ? n - 1 - xi : xi)];
+  dst[((long long)b * n + y) * n + x] = v;
+}
+
+__global__ __launch_bounds__(256) void k_img_sum(const unsigned char* __restrict__ img, int count, unsigned long long* __restrict__ sums) {
+  const int b = blockIdx.y;
+  const unsigned char* S = img + (long long)b * count;
+  unsigned long long s = 0;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) s += S[i];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if ((threadIdx.x & 63) == 0 && s) atomicAdd(&sums[b], s);          // integer adds: exact in any order
+}
+
+// kind[b]: 0 none, 1 brightness (degenerate = 0), 2 contrast (degenerate = int(mean + 0.5)); alpha[b]: the factor as a C
+// float.  PIL Blend.c: out = (UINT8)((int)deg + alpha * ((int)in - (int)deg)), clipped when alpha is outside [0, 1].
+__global__ __launch_bounds__(256) void k_aug_blend(unsigned char* __restrict__ img, int count, const int* __restrict__ kind,
+                                                   const float* __restrict__ alpha, const unsigned long long* __restrict__ sums) {
+  const int b = blockIdx.y, k = kind[b];
+  if (k == 0) return;
+  const float a = alpha[b];
+  if (a == 1.0f) return;                                            // ImagingCopy(image)
+  int g = 0;
+  if (k == 2) g = (int)add_(div_((double)sums[b], (double)count), 0.5);
+  unsigned char* S = img + (long long)b * count;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
+    const int v = S[i];
+    int o;
+    if (a == 0.0f) {
+      o = g;
+    } else {
+      const float t = add_((float)g, mul_(a, (float)(v - g)));
+      if (a >= 0.f && a <= 1.f) o = (int)t;
+      else o = t <= 0.f ? 0 : (t >= 255.f ? 255 : (int)t);
+    }
+    S[i] = (unsigned char)o;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_u8_to_tensor(const unsigned char* __restrict__ img, int count, float* __restrict__ out) {
+  const int b = blockIdx.y;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
+    const float t = div_((float)img[(long long)b * count + i], 255.0f);       // ToTensor
+    const float o = div_(sub_(t, 0.5f), 0.5f);                                 // Normalize(0.5, 0.5)
+    float* d = out + (long long)b * 3 * count + i;
+    d[0] = o;
+    d[count] = o;
+    d[2 * (long long)count] = o;
+  }
+}
+
 }  // namespace
+
+extern "C" int glr_aug_geom(const uint8_t* src, uint8_t* dst, int B, int size, const int32_t* flip, const double* matrix,
+                            void* stream) {
+  if (!src || !dst || src == dst || !flip || B <= 0 || size <= 0 || size > 256) return GLR_EINVAL;
+  hipLaunchKernelGGL(k_aug_geom, dim3(size, B), dim3(256), 0, static_cast<hipStream_t>(stream), src, dst, size, flip, matrix);
+  GLR_CHECK_LAUNCH();
+  return GLR_OK;
+}
+
+extern "C" int glr_aug_jitter(uint8_t* img, int B, int size, const int32_t* kind, const float* alpha, uint64_t* sums_ws,
+                              void* stream) {
+  if (!img || !kind || !alpha || !sums_ws || B <= 0 || size <= 0 || size > 256) return GLR_EINVAL;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int count = size * size;
+  if (hipMemsetAsync(sums_ws, 0, sizeof(uint64_t) * B, st) != hipSuccess) return GLR_ELAUNCH;
+  const int blocks = (count + 256 * 8 - 1) / (256 * 8);
+  hipLaunchKernelGGL(k_img_sum, dim3(blocks, B), dim3(256), 0, st, img, count, reinterpret_cast<unsigned long long*>(sums_ws));
+  GLR_CHECK_LAUNCH();
+  hipLaunchKernelGGL(k_aug_blend, dim3(blocks, B), dim3(256), 0, st, img, count, kind, alpha,
+                     reinterpret_cast<const unsigned long long*>(sums_ws));
+  GLR_CHECK_LAUNCH();
+  return GLR_OK;
+}
+
+extern "C" int glr_u8_to_tensor(const uint8_t* img, int B, int size, float* out, void* stream) {
+  if (!img || !out || B <= 0 || size <= 0 || size > 256) return GLR_EINVAL;
+  const int count = size * size;
+  hipLaunchKernelGGL(k_u8_to_tensor, dim3((count + 2047) / 2048, B), dim3(256), 0, static_cast<hipStream_t>(stream), img, count, out);
+  GLR_CHECK_LAUNCH();
+  return GLR_OK;
+}
 
 extern "C" int glr_image_minmax(const void* src, const int64_t* offset, const int32_t* desc, int B, int src_dtype,
                                 uint32_t* state, void* stream) {
@@ -374,16 +534,17 @@ extern "C" int glr_image_minmax(const void* src, const int64_t* offset, const in
 }
 
 extern "C" int glr_collate_images(const void* src, const int64_t* offset, const int32_t* desc,
-                                  const uint32_t* state, int B, int src_dtype, int crop, float* out, void* stream) {
-  if (!src || !offset || !desc || !out || B <= 0 || crop <= 0 || crop > 256) return GLR_EINVAL;
+                                  const uint32_t* state, int B, int src_dtype, int crop, float* out, uint8_t* out_u8,
+                                  void* stream) {
+  if (!src || !offset || !desc || (!out == !out_u8) || B <= 0 || crop <= 0 || crop > 256) return GLR_EINVAL;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const unsigned char* s = static_cast<const unsigned char*>(src);
   const long long* off = reinterpret_cast<const long long*>(offset);
   dim3 grid(crop, B);
 #define GLR_COLLATE(T)                                                                                         \
   do {                                                                                                         \
-    if (state) hipLaunchKernelGGL((k_collate<T, true>), grid, dim3(256), 0, st, s, off, desc, state, crop, out); \
-    else hipLaunchKernelGGL((k_collate<T, false>), grid, dim3(256), 0, st, s, off, desc, state, crop, out);      \
+    if (state) hipLaunchKernelGGL((k_collate<T, true>), grid, dim3(256), 0, st, s, off, desc, state, crop, out, out_u8); \
+    else hipLaunchKernelGGL((k_collate<T, false>), grid, dim3(256), 0, st, s, off, desc, state, crop, out, out_u8);      \
   } while (0)
   switch (src_dtype) {
     case GLR_SRC_U8: GLR_COLLATE(unsigned char); break;

@@ -16,8 +16,13 @@ image half on the GPU.
   get_segmentation_labels       :110-118  boxes -> bool [B, crop, crop] labels; host integers / tap tables instead of
         one full-resolution mask image per box (see `resized_box_mask`)
 
-Not built: the random flip / affine / colour transforms of builder.py:167-186 (unused by configs/imagenome_pretrain_config.yaml), images smaller than `imsize`
-(cv2 would upscale with its bilinear branch).  There is no CPU path: process_img needs the HIP library and a GPU.
+  random transforms             builder.py:167-186  RandomHorizontalFlip / RandomAffine / ColorJitter(brightness,
+        contrast) of torchvision 0.8.2 on the cropped PIL image (no config of the reference enables them): the
+        PARAMETERS are drawn on the host in torchvision's order (`draw_augmentation`; torchvision is not installed here,
+        the draw order and the matrix formula are restated from its source: parity unpinned), the pixels are transformed
+        on the GPU with Pillow's arithmetic (glr_aug_geom / glr_aug_jitter / glr_u8_to_tensor, include/glr.h).
+Images smaller than `imsize` are enlarged the way cv2.INTER_AREA does it (fixed-point bilinear emulation).
+There is no CPU path: process_img needs the HIP library and a GPU.
 """
 
 import math
@@ -46,9 +51,98 @@ def resize_plan(h, w, scale):
     return dh, dw, int(math.floor((scale - dh) / 2)), 0
 
 
-def collate_images(images, crop_offsets, scale=256, crop=224, device="cuda", minmax=None):
+def inverse_affine_matrix(center, angle, translate, scale, shear=(0.0, 0.0)):
+    """torchvision 0.8.2 functional._get_inverse_affine_matrix (called by F.affine with center = (w * 0.5, h * 0.5)):
+    the six coefficients PIL's Image.transform(AFFINE) takes - output pixel -> input position."""
+    rot = math.radians(angle)
+    sx, sy = math.radians(shear[0]), math.radians(shear[1])
+    cx, cy = center
+    tx, ty = translate
+    a = math.cos(rot - sy) / math.cos(sy)
+    b = -math.cos(rot - sy) * math.tan(sx) / math.cos(sy) - math.sin(rot)
+    c = math.sin(rot - sy) / math.cos(sy)
+    d = -math.sin(rot - sy) * math.tan(sx) / math.cos(sy) + math.cos(rot)
+    m = [v / scale for v in (d, -b, 0.0, -c, a, 0.0)]
+    m[2] += m[0] * (-cx - tx) + m[1] * (-cy - ty)
+    m[5] += m[3] * (-cx - tx) + m[4] * (-cy - ty)
+    m[2] += cx
+    m[5] += cy
+    return m
+
+
+def draw_augmentation(flip_p, affine, jitter, size):
+    """One image's random transform parameters, drawn from torch's global generator in the order torchvision 0.8.2's
+    Compose([RandomHorizontalFlip, RandomAffine, ColorJitter]) draws them (restated from its source, unpinned):
+      flip     torch.rand(1) < p
+      affine   RandomAffine.get_params: angle, then tx, ty (rounded to whole pixels), then scale - each
+               torch.empty(1).uniform_(lo, hi)
+      jitter   fn_idx = torch.randperm(4); brightness (0) / contrast (1) factor torch.tensor(1.0).uniform_(lo, hi) in
+               that order (saturation / hue are not configured by builder.py:178-184)
+    flip_p: float | None; affine: None | dict(degrees, translate, scale); jitter: None | dict(brightness, contrast) of
+    [lo, hi] pairs.  Returns the dict collate_images / the oracle's `augment` take."""
+    aug = {"flip": False, "affine": None, "jitter": []}
+    if flip_p is not None:
+        aug["flip"] = bool(torch.rand(1) < flip_p)
+    if affine is not None:
+        deg = affine["degrees"]
+        deg = (-float(deg), float(deg)) if isinstance(deg, (int, float)) else (float(deg[0]), float(deg[1]))
+        angle = float(torch.empty(1).uniform_(deg[0], deg[1]).item())
+        tx = ty = 0
+        if affine.get("translate") is not None:
+            max_dx, max_dy = float(affine["translate"][0] * size), float(affine["translate"][1] * size)
+            tx = int(round(torch.empty(1).uniform_(-max_dx, max_dx).item()))
+            ty = int(round(torch.empty(1).uniform_(-max_dy, max_dy).item()))
+        sc = 1.0
+        if affine.get("scale") is not None:
+            sc = float(torch.empty(1).uniform_(float(affine["scale"][0]), float(affine["scale"][1])).item())
+        aug["affine"] = (angle, (tx, ty), sc)
+    if jitter is not None:
+        for fn_id in torch.randperm(4).tolist():
+            for k, name in ((0, "brightness"), (1, "contrast")):
+                rng_ = jitter.get(name)
+                if fn_id == k and rng_ is not None:
+                    aug["jitter"].append((name, float(torch.tensor(1.0).uniform_(float(rng_[0]), float(rng_[1])).item())))
+    return aug
+
+
+def _apply_augmentation(u8, augs, crop, device):
+    """uint8 [B, crop, crop] on the GPU -> float32 [B, 3, crop, crop]: flip + affine, the colour steps, ToTensor + Normalize"""
+    L = N.lib()
+    B = u8.shape[0]
+    flip = np.array([1 if a.get("flip") else 0 for a in augs], dtype=np.int32)
+    mats = np.full((B, 6), np.nan, dtype=np.float64)
+    for b, a in enumerate(augs):
+        if a.get("affine") is not None:
+            angle, translate, sc = a["affine"]
+            mats[b] = inverse_affine_matrix((crop * 0.5, crop * 0.5), angle, translate, sc)
+    if flip.any() or not np.isnan(mats[:, 0]).all():
+        dst = torch.empty_like(u8)
+        flip_d, mats_d = N.upload(flip, device), N.upload(mats, device)      # named: alive until the launch is queued
+        N.check(L.glr_aug_geom(N.ptr(u8), N.ptr(dst), B, crop, N.ptr(flip_d), N.ptr(mats_d), N.stream()), "glr_aug_geom")
+        u8 = dst
+    steps = max((len(a.get("jitter", ())) for a in augs), default=0)
+    if steps:
+        sums = torch.empty(B, dtype=torch.int64, device=device)
+        code = {"brightness": 1, "contrast": 2}
+        for j in range(steps):
+            kind = np.zeros(B, dtype=np.int32)
+            alpha = np.ones(B, dtype=np.float32)
+            for b, a in enumerate(augs):
+                jit = a.get("jitter", ())
+                if j < len(jit):
+                    kind[b], alpha[b] = code[jit[j][0]], jit[j][1]
+            kind_d, alpha_d = N.upload(kind, device), N.upload(alpha, device)
+            N.check(L.glr_aug_jitter(N.ptr(u8), B, crop, N.ptr(kind_d), N.ptr(alpha_d), N.ptr(sums), N.stream()),
+                    "glr_aug_jitter")
+    out = torch.empty(B, 3, crop, crop, dtype=torch.float32, device=device)
+    N.check(L.glr_u8_to_tensor(N.ptr(u8), B, crop, N.ptr(out), N.stream()), "glr_u8_to_tensor")
+    return out
+
+
+def collate_images(images, crop_offsets, scale=256, crop=224, device="cuda", minmax=None, augs=None):
     """images: list of 2-D numpy arrays / torch tensors.  uint8 images are taken as they are (minmax=False) unless
-    minmax=True; other dtypes are min-max normalised to uint8 on the GPU.  Returns float32 [B, 3, crop, crop]."""
+    minmax=True; other dtypes are min-max normalised to uint8 on the GPU.  augs: None, or one `draw_augmentation` dict
+    per image (flip / affine / colour steps between the crop and ToTensor).  Returns float32 [B, 3, crop, crop]."""
     arrs = []
     for im in images:
         a = im.detach().cpu().numpy() if isinstance(im, torch.Tensor) else np.asarray(im)
@@ -69,8 +163,6 @@ def collate_images(images, crop_offsets, scale=256, crop=224, device="cuda", min
     total = 0
     for b, (a, (cy, cx)) in enumerate(zip(arrs, crop_offsets)):
         h, w = a.shape
-        if max(h, w) < scale:
-            raise NotImplementedError(f"image {h}x{w} is smaller than imsize={scale}: cv2 would upscale (not built)")
         dh, dw, top, left = resize_plan(h, w, scale)
         if dh <= 0 or dw <= 0:
             raise ValueError(f"degenerate image {h}x{w}")
@@ -88,7 +180,10 @@ def collate_images(images, crop_offsets, scale=256, crop=224, device="cuda", min
     N.require_cuda(src)
     meta = torch.from_numpy(np.concatenate([offsets.view(np.int32), desc.reshape(-1)])).to(device, non_blocking=True)
     off_d, desc_d = meta[:2 * len(arrs)], meta[2 * len(arrs):]
-    out = torch.empty(len(arrs), 3, crop, crop, dtype=torch.float32, device=device)
+    if augs is not None and len(augs) != len(arrs):
+        raise ValueError("one augmentation record per image")
+    out = torch.empty(len(arrs), 3, crop, crop, dtype=torch.float32, device=device) if augs is None else None
+    u8 = torch.empty(len(arrs), crop, crop, dtype=torch.uint8, device=device) if augs is not None else None
     L = N.lib()
     code = _SRC_CODE[dt]
     state = None
@@ -97,7 +192,9 @@ def collate_images(images, crop_offsets, scale=256, crop=224, device="cuda", min
         N.check(L.glr_image_minmax(N.ptr(src), N.ptr(off_d), N.ptr(desc_d), len(arrs), code, N.ptr(state), N.stream()),
                 "glr_image_minmax")
     N.check(L.glr_collate_images(N.ptr(src), N.ptr(off_d), N.ptr(desc_d), N.ptr(state), len(arrs), code, crop,
-                                 N.ptr(out), N.stream()), "glr_collate_images")
+                                 N.ptr(out), N.ptr(u8), N.stream()), "glr_collate_images")
+    if augs is not None:
+        return _apply_augmentation(u8, augs, crop, device)
     return out
 
 
@@ -224,9 +321,19 @@ class GloriaCollateFn:
         self.ixtoword = {v: k for k, v in self.tokenizer.get_vocab().items()}
         self.include_instances = include_instances
         t = cfg.transforms
-        for name in ("random_horizontal_flip", "random_affine", "color_jitter"):
-            if t is not None and getattr(t, name) is not None:
-                raise NotImplementedError(f"transforms.{name} is not built (builder.py:167-186)")
+        # builder.py:167-186: the random transforms exist for the train split only
+        self.flip_p = self.affine = self.jitter = None
+        if t is not None and split == "train":
+            if getattr(t, "random_horizontal_flip", None) is not None:
+                self.flip_p = float(t.random_horizontal_flip)
+            ra = getattr(t, "random_affine", None)
+            if ra is not None:
+                self.affine = {"degrees": ra.degrees, "translate": list(ra.translate), "scale": list(ra.scale)}
+            cj = getattr(t, "color_jitter", None)
+            if cj is not None:          # `bightness` is the reference's spelling of the key (builder.py:181)
+                rng_b, rng_c = [float(v) for v in cj.bightness], [float(v) for v in cj.contrast]
+                self.jitter = {"brightness": None if rng_b[0] == rng_b[1] == 1.0 else rng_b,
+                               "contrast": None if rng_c[0] == rng_c[1] == 1.0 else rng_c}
         if t is None or t.norm != "half":
             raise NotImplementedError("only Normalize(0.5, 0.5) ('half') is built (builder.py:196-197)")
         self.scale = cfg.data.image.imsize
@@ -245,7 +352,26 @@ class GloriaCollateFn:
         o = int(round(room / 2.0))
         return [(o, o)] * n
 
+    def augmented(self):
+        return self.flip_p is not None or self.affine is not None or self.jitter is not None
+
+    def draw_params(self, n):
+        """crop offsets and transform parameters of n images in the reference's order: the Compose runs per image, so
+        image b's crop, flip, affine and colour draws all come before image b + 1's"""
+        room = self.scale - self.crop
+        crops, augs = [], []
+        for _ in range(n):
+            if room == 0:
+                crops.append((0, 0))
+            else:
+                crops.append((int(torch.randint(0, room + 1, size=(1,)).item()), int(torch.randint(0, room + 1, size=(1,)).item())))
+            augs.append(draw_augmentation(self.flip_p, self.affine, self.jitter, self.crop))
+        return crops, augs
+
     def process_img(self, images, device, minmax=None):
+        if self.augmented():
+            crops, augs = self.draw_params(len(images))
+            return collate_images(images, crops, self.scale, self.crop, device, minmax, augs)
         return collate_images(images, self.crop_offsets(len(images)), self.scale, self.crop, device, minmax)
 
     # ---- text

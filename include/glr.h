@@ -437,20 +437,35 @@ int glr_attn_bwd(const void* q, const void* k, const void* v, const void* o, con
  * src     one device buffer holding the B images back to back (row-major H x W, element type src_dtype);
  * offset  [B] device int64: byte offset of each image in src (16-byte aligned offsets use vector loads);
  * desc    [B][8] device int32 per image: { H, W, dst_h, dst_w, pad_top, pad_left, crop_top, crop_left } where
- *         dst_h x dst_w is the resized size (<= H x W: downscaling only), pad_* its position in the scale x scale
+ *         dst_h x dst_w is the resized size (smaller OR larger than H x W), pad_* its position in the scale x scale
  *         frame and crop_* the crop window's corner in that frame (host planning: gloria/datasets/collate.py);
  * state   [B][2] device uint32: per-image min / max as order-preserving keys, written by glr_image_minmax and read
  *         by glr_collate_images; NULL = src already holds the 8-bit image (src_dtype GLR_SRC_U8);
- * out     float32 [B, 3, crop, crop] (crop <= 256), values in [-1, 1], three equal channels.
+ * out     float32 [B, 3, crop, crop] (crop <= 256), values in [-1, 1], three equal channels; or
+ * out_u8  uint8 [B, crop, crop]: the cropped 8-bit image, input of the transform passes below (exactly one of the two).
  * One thread per output pixel evaluates OpenCV 4.5's INTER_AREA cell (integer-scale fast path incl. the 2x2 8-bit
- * rounding, general fp32 tap path in OpenCV's summation order) from the source directly: no intermediate image is
- * materialised and only pixels under the crop window are read.  Bit-exact against oracle/collate_oracle.py;
+ * rounding, general fp32 tap path in OpenCV's summation order; when the image is enlarged: cv::resize's fixed-point
+ * bilinear emulation with area coordinates) from the source directly: no intermediate image is materialised and only
+ * pixels under the crop window are read.  Bit-exact against oracle/collate_oracle.py;
  * HBM-bound (algorithmic bytes: H*W*esz read once for min-max, <= H*W*esz read + 12*crop^2 written by the collate).
+ *
+ * Random transforms of gloria/builder.py:167-186 (torchvision 0.8.2 RandomHorizontalFlip / RandomAffine / ColorJitter
+ * on the PIL image; parameters drawn on the HOST - gloria/datasets/collate.py draw_augmentation) on uint8 [B, size, size]:
+ *   glr_aug_geom     dst = affine(flip(src)): flip [B] int32 (non-zero = mirrored), matrix [B][6] float64 = the
+ *                    coefficients PIL's Image.transform(AFFINE) takes (NaN in [0] = no affine; NULL = none at all),
+ *                    nearest neighbour, zero fill, PIL's arithmetic (Geometry.c ImagingScaleAffine / affine_fixed)
+ *   glr_aug_jitter   in place, ONE ImageEnhance step per call: kind [B] int32 (0 none, 1 brightness, 2 contrast),
+ *                    alpha [B] float (the factor); sums_ws [B] uint64 scratch (per-image grey sums for the contrast mean)
+ *   glr_u8_to_tensor ToTensor + Normalize(0.5, 0.5): float32 [B, 3, size, size]
+ * Bit-exact against oracle/collate_oracle.py, whose Pillow half is pinned against Pillow itself in the CPU tests.
  */
 int glr_image_minmax(const void* src, const int64_t* offset, const int32_t* desc, int B, int src_dtype,
                      uint32_t* state, void* stream);
 int glr_collate_images(const void* src, const int64_t* offset, const int32_t* desc, const uint32_t* state, int B,
-                       int src_dtype, int crop, float* out, void* stream);
+                       int src_dtype, int crop, float* out, uint8_t* out_u8, void* stream);
+int glr_aug_geom(const uint8_t* src, uint8_t* dst, int B, int size, const int32_t* flip, const double* matrix, void* stream);
+int glr_aug_jitter(uint8_t* img, int B, int size, const int32_t* kind, const float* alpha, uint64_t* sums_ws, void* stream);
+int glr_u8_to_tensor(const uint8_t* img, int B, int size, float* out, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Optimisation step over FLAT parameter buffers (the reference delegates it to Lightning: Adam(betas=(0.5, 0.999)),

@@ -90,8 +90,8 @@ def test_process_img_layout_and_range():
     assert (out[0, 0, : top - 3] == -1).all()
     frame = co.resize_img(imgs[1], 256)
     np.testing.assert_array_equal(out[1, 0], (frame[16:240, 16:240].astype(np.float32) / np.float32(255) - np.float32(0.5)) / np.float32(0.5))
-    with pytest.raises(ValueError):
-        co.resize_img(np.zeros((100, 200), dtype=np.uint8), 256)
+    small = co.resize_img(np.full((100, 200), 9, dtype=np.uint8), 256)   # long side below imsize: enlarged, then padded
+    assert small.shape == (256, 256) and (small[64:192] == 9).all() and (small[:64] == 0).all() and (small[192:] == 0).all()
 
 
 # ---------------------------------------------------------------- text half (host logic of the product)
@@ -154,8 +154,89 @@ def test_collate_images_needs_the_gpu(collate_fn):
         pytest.skip("GPU present")
     with pytest.raises(RuntimeError):
         collate_fn.process_img([np.zeros((300, 300), dtype=np.uint8)], "cpu")
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(RuntimeError):                      # small images are enlarged - on the GPU like the others
         collate_fn.process_img([np.zeros((100, 100), dtype=np.uint8)], "cpu")
+
+
+# ---------------------------------------------------------------- enlarging branch of cv2.INTER_AREA (oracle; unpinned)
+def test_enlarging_resize_known_answers():
+    # worked by hand from cv::resize's coefficient loop (area_mode, 11-bit fixed point), see the oracle's docstring
+    assert co.resize_area_u8(np.array([[0, 255]], np.uint8), 1, 4).tolist() == [[0, 0, 255, 255]]
+    assert co.resize_area_u8(np.array([[0, 255]], np.uint8), 1, 3).tolist() == [[0, 128, 255]]
+    assert co.resize_area_u8(np.array([[0], [255]], np.uint8), 3, 1).tolist() == [[0], [128], [255]]
+    rng = np.random.default_rng(5)
+    const = np.full((50, 60), 77, np.uint8)
+    assert (co.resize_area_u8(const, 213, 256) == 77).all()
+    img = rng.integers(0, 256, (90, 120), dtype=np.uint8)
+    up = co.resize_area_u8(img, 192, 256)
+    assert up.shape == (192, 256) and up.min() >= img.min() and up.max() <= img.max()       # convex combinations
+    assert abs(float(up.mean()) - float(img.mean())) < 1.0
+    frame = co.resize_img(img, 256)                                                          # 90 x 120 -> 192 x 256, padded
+    assert frame.shape == (256, 256) and (frame[:32] == 0).all() and (frame[224:] == 0).all()
+    assert np.array_equal(frame[32:224], up)
+    # one direction enlarged, the other kept: the x coefficients degenerate to a copy
+    tall = rng.integers(0, 256, (40, 256), dtype=np.uint8)
+    assert np.array_equal(co.resize_area_u8(tall, 80, 256)[::2], tall)
+
+
+# ---------------------------------------------------------------- random transforms: the oracle against Pillow itself
+def test_transform_oracle_matches_pillow():
+    PIL = pytest.importorskip("PIL")
+    from PIL import Image, ImageEnhance
+    rng = np.random.default_rng(0)
+    for size in (224, 97):
+        img = rng.integers(0, 256, (size, size), dtype=np.uint8)
+        pil = Image.fromarray(img, "L").convert("RGB")                # process_img: PIL "L" -> "RGB" (:127-128)
+        assert np.array_equal(np.asarray(pil.transpose(Image.FLIP_LEFT_RIGHT))[..., 0], co.hflip(img))
+        c = size * 0.5
+        for angle, tr, sc in [(0.0, (5, -7), 1.1), (0.0, (0, 0), 0.9), (12.5, (3, 4), 1.05), (-30.0, (-10, 8), 0.95),
+                              (90.0, (0, 0), 1.0), (0.0, (0, 0), 1.0), (7.3, (22, -22), 1.2), (179.9, (1, 1), 0.8)]:
+            m = co.inverse_affine_matrix((c, c), angle, tr, sc)
+            ref = np.asarray(pil.transform(pil.size, Image.AFFINE, m, Image.NEAREST))
+            got = co.affine_nearest_u8(img, m)
+            assert np.array_equal(ref[..., 0], got) and np.array_equal(ref[..., 2], got), (size, angle, tr, sc)
+        for f in [0.0, 1.0, 0.3, 0.8, 0.9999, 1.2, 1.7, 0.123456789, 2.5]:
+            assert np.array_equal(np.asarray(ImageEnhance.Brightness(pil).enhance(f))[..., 0], co.adjust_brightness(img, f)), f
+            assert np.array_equal(np.asarray(ImageEnhance.Contrast(pil).enhance(f))[..., 0], co.adjust_contrast(img, f)), f
+    # Compose order: flip -> affine -> colour steps as drawn
+    aug = {"flip": True, "affine": (10.0, (4, -3), 1.1), "jitter": [("contrast", 1.3), ("brightness", 0.7)]}
+    ref = pil.transpose(Image.FLIP_LEFT_RIGHT)
+    ref = ref.transform(ref.size, Image.AFFINE, co.inverse_affine_matrix((c, c), 10.0, (4, -3), 1.1), Image.NEAREST)
+    ref = ImageEnhance.Brightness(ImageEnhance.Contrast(ref).enhance(1.3)).enhance(0.7)
+    assert np.array_equal(np.asarray(ref)[..., 1], co.augment(img, aug))
+
+
+def test_augmentation_draws_follow_torchvision_order(collate_fn):
+    from gloria.datasets import collate as C
+    torch.manual_seed(11)
+    got = C.draw_augmentation(0.5, {"degrees": 10, "translate": [0.1, 0.05], "scale": [0.9, 1.1]},
+                              {"brightness": [0.8, 1.2], "contrast": [0.7, 1.3]}, 224)
+    torch.manual_seed(11)
+    flip = bool(torch.rand(1) < 0.5)
+    angle = float(torch.empty(1).uniform_(-10.0, 10.0).item())
+    tx = int(round(torch.empty(1).uniform_(-22.4, 22.4).item()))
+    ty = int(round(torch.empty(1).uniform_(-11.2, 11.2).item()))
+    sc = float(torch.empty(1).uniform_(0.9, 1.1).item())
+    jit = []
+    for fn_id in torch.randperm(4).tolist():
+        if fn_id == 0:
+            jit.append(("brightness", float(torch.tensor(1.0).uniform_(0.8, 1.2).item())))
+        if fn_id == 1:
+            jit.append(("contrast", float(torch.tensor(1.0).uniform_(0.7, 1.3).item())))
+    assert got == {"flip": flip, "affine": (angle, (tx, ty), sc), "jitter": jit}
+    assert len(jit) == 2 and -10 <= angle <= 10 and abs(tx) <= 23 and abs(ty) <= 12
+    # the collate function takes the reference's transform keys (builder.py:167-186, `bightness` spelled as there)
+    cfg = collate_fn.cfg
+    cfg.set_path("transforms.random_horizontal_flip", 0.5)
+    cfg.set_path("transforms.random_affine", {"degrees": 10, "translate": [0.1, 0.1], "scale": [0.9, 1.1]})
+    cfg.set_path("transforms.color_jitter", {"bightness": [0.8, 1.2], "contrast": [1.0, 1.0]})
+    fn = C.GloriaCollateFn(cfg, "train", device="cpu", tokenizer=collate_fn.tokenizer)
+    assert fn.augmented() and fn.jitter == {"brightness": [0.8, 1.2], "contrast": None}
+    crops, augs = fn.draw_params(3)
+    assert len(crops) == len(augs) == 3 and all(len(a["jitter"]) == 1 for a in augs)
+    assert not C.GloriaCollateFn(cfg, "valid", device="cpu", tokenizer=collate_fn.tokenizer).augmented()
+    for k in ("random_horizontal_flip", "random_affine", "color_jitter"):
+        cfg.set_path("transforms." + k, None)
 
 
 # ---------------------------------------------------------------- segmentation labels from boxes (host logic)

@@ -51,6 +51,59 @@ def test_collate_bit_exact(dtype, minmax):
     assert not bad, [(SHAPES[i], float(np.abs(got[i] - want[i]).max()) * 127.5) for i in bad]
 
 
+SMALL = [(100, 80), (255, 255), (64, 250), (250, 64), (17, 23), (200, 256), (256, 130), (1, 1), (2, 255)]
+
+
+@pytest.mark.parametrize("dtype,minmax", [(np.uint8, False), (np.int16, True), (np.float32, True)])
+def test_enlarged_images_bit_exact(dtype, minmax):
+    """long side below imsize: cv2.INTER_AREA's bilinear emulation (mode 3 of k_collate) against resize_area_up_u8"""
+    from gloria.datasets.collate import collate_images
+    rng = np.random.default_rng(9)
+    imgs = []
+    for h, w in SMALL:
+        if dtype == np.uint8:
+            imgs.append(rng.integers(0, 256, size=(h, w), dtype=np.uint8))
+        elif dtype == np.int16:
+            imgs.append(rng.integers(-1024, 3072, size=(h, w)).astype(np.int16))
+        else:
+            imgs.append((rng.standard_normal((h, w)) * 417.3 + 1000).astype(np.float32))
+    if minmax:
+        imgs[7] = np.array([[3]], dtype=dtype)                 # constant image: defined as grey level 0
+    offs = offsets(len(imgs))
+    got = collate_images(imgs, offs, 256, 224, "cuda", minmax=minmax).cpu().numpy()
+    u8 = [co.to_u8(a) if minmax else a for a in imgs]
+    if minmax:
+        u8[7] = np.zeros((1, 1), np.uint8)
+    want = co.process_img(u8, offs, 256, 224)
+    bad = [i for i in range(len(imgs)) if not np.array_equal(got[i], want[i])]
+    assert not bad, [(SMALL[i], float(np.abs(got[i] - want[i]).max()) * 127.5) for i in bad]
+
+
+def test_random_transforms_bit_exact():
+    """flip / affine (PIL's scaling special case and its 16.16 fixed-point path) / brightness / contrast in both orders,
+    interpolating and extrapolating factors: the device passes against the oracle (itself pinned against Pillow)"""
+    from gloria.datasets.collate import collate_images
+    imgs = images(np.uint8)[:8] + [np.random.default_rng(2).integers(0, 256, size=(120, 90), dtype=np.uint8)]
+    offs = offsets(len(imgs))
+    augs = [
+        {"flip": True, "affine": None, "jitter": []},
+        {"flip": False, "affine": (0.0, (7, -5), 1.1), "jitter": []},                       # scaling path
+        {"flip": True, "affine": (12.5, (3, 4), 0.95), "jitter": [("brightness", 0.8)]},     # fixed-point path
+        {"flip": False, "affine": (-30.0, (-10, 8), 1.05), "jitter": [("contrast", 1.3), ("brightness", 0.7)]},
+        {"flip": False, "affine": None, "jitter": [("brightness", 1.4), ("contrast", 0.6)]},
+        {"flip": True, "affine": (90.0, (0, 0), 1.0), "jitter": [("contrast", 0.0)]},
+        {"flip": False, "affine": (0.0, (0, 0), 0.9), "jitter": [("contrast", 1.0), ("brightness", 0.0)]},
+        {"flip": False, "affine": None, "jitter": []},
+        {"flip": True, "affine": (5.0, (20, -20), 1.2), "jitter": [("contrast", 2.0)]},
+    ]
+    got = collate_images(imgs, offs, 256, 224, "cuda", minmax=False, augs=augs).cpu().numpy()
+    want = co.process_img(imgs, offs, 256, 224, augs=augs)
+    bad = [i for i in range(len(imgs)) if not np.array_equal(got[i], want[i])]
+    assert not bad, [(i, int((got[i] != want[i]).sum())) for i in bad]
+    plain = collate_images(imgs, offs, 256, 224, "cuda", minmax=False).cpu().numpy()
+    assert np.array_equal(plain[7], got[7])                                                  # no transform = the plain path
+
+
 def test_minmax_state_and_constant_image():
     from gloria import _native as N
     from gloria.datasets.collate import collate_images
@@ -64,7 +117,7 @@ def test_minmax_state_and_constant_image():
     cols = np.arange(16, 240)
     inside = (cols >= left) & (cols < left + dw)
     assert (out[0, :, :, inside] == val).all() and (out[0, :, :, ~inside] == -1).all()
-    assert N.lib().glr_collate_images(None, None, None, None, 1, 0, 224, None, None) == -1
+    assert N.lib().glr_collate_images(None, None, None, None, 1, 0, 224, None, None, None) == -1
 
 
 def test_full_size_batch_properties():
@@ -127,7 +180,7 @@ def test_rows_staged_in_chunks_and_unaligned_fallback():
     out = torch.empty(1, 3, 224, 224, device="cuda")
     L = N.lib()
     N.check(L.glr_image_minmax(N.ptr(buf), N.ptr(off), N.ptr(desc), 1, 1, N.ptr(state), N.stream()), "minmax")
-    N.check(L.glr_collate_images(N.ptr(buf), N.ptr(off), N.ptr(desc), N.ptr(state), 1, 1, 224, N.ptr(out), N.stream()), "collate")
+    N.check(L.glr_collate_images(N.ptr(buf), N.ptr(off), N.ptr(desc), N.ptr(state), 1, 1, 224, N.ptr(out), None, N.stream()), "collate")
     assert np.array_equal(out.cpu().numpy(), co.process_img([co.to_u8(img)], [(11, 3)]))
 
 

@@ -27,7 +27,7 @@ def main(B=64, H=3056, W=2544, reps=10):
         N.check(L.glr_image_minmax(N.ptr(src), N.ptr(off), N.ptr(desc), B, 1, N.ptr(state), st), "minmax")
 
     def col():
-        N.check(L.glr_collate_images(N.ptr(src), N.ptr(off), N.ptr(desc), N.ptr(state), B, 1, 224, N.ptr(out), st), "collate")
+        N.check(L.glr_collate_images(N.ptr(src), N.ptr(off), N.ptr(desc), N.ptr(state), B, 1, 224, N.ptr(out), None, st), "collate")
 
     for name, fn, nbytes in (("glr_image_minmax", mm, B * n * 2), ("glr_collate_images", col, B * n * 2 * (224 / 256) ** 2 + out.numel() * 4)):
         fn(); torch.cuda.synchronize()
