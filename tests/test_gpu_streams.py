@@ -35,6 +35,7 @@ def _run(streams, dctx):
     torch.cuda.manual_seed(17)
     loss = float(tr.training_step(model, batch, 0))
     torch.cuda.synchronize()
+    _check_clip(tr)
     grads = {}
     if tr.reducer is not None:                 # data parallel: the gathered + reduced flat gradient buffers
         for k, g in enumerate(tr.optimizer.groups):
@@ -45,7 +46,17 @@ def _run(streams, dctx):
                 grads[n] = p.grad.float().cpu()
     bn = {n: b.float().cpu().clone() for n, b in model.named_buffers() if "running_" in n}
     loss2 = float(tr.training_step(model, batch, 1))                       # carries step 0's update of every parameter
+    _check_clip(tr)
     return loss, loss2, grads, bn
+
+
+def _check_clip(tr):
+    """[global gradient norm, clip coefficient] of the step just taken: a garbage gradient anywhere shows as an infinite /
+    NaN norm and a zero (update skipped) or unit (update unclipped) coefficient - the signature of the hipGraph replay
+    race of round 3 (gloria/hipgraph.py), which left the loss of that very step untouched"""
+    norm, coef = (float(v) for v in tr.optimizer.clip_state.float().cpu())
+    assert np.isfinite(norm) and 1.0 < norm < 1e4, norm
+    assert 0.0 < coef < 1.0 and abs(coef * norm - tr.clip) < 1e-3 * tr.clip, (norm, coef)
 
 
 def _compare(a, b):
@@ -205,6 +216,49 @@ def test_image_graph_replays_stay_correct_in_a_backward_loop():
             # two eager passes differ by up to ~7 % here (bf16 gradients through 50 layers, split-K atomics in the
             # weight-gradient solvers); the race gave inf / NaN / orders of magnitude
             assert rel < 0.2, (it, n, rel)
+
+
+@pytest.mark.parametrize("streams", [False, True])
+def test_data_parallel_steps_converge_with_both_graphs(monkeypatch, streams):
+    """four optimisation steps on the data-parallel path (single-rank RCCL group) with both encoder graphs on: the loss
+    must fall like in single-process eager training and every step's gradient norm must be finite - with the racy replay
+    the loss stayed at 21.6 (update skipped every step) on two streams and the flat buffers held NaN on one"""
+    import torch.distributed as dist
+    from gloria import builder, dist as gdist
+    from gloria.config import pretrain_config
+    from gloria.datasets.synthetic import make_batch
+    from gloria.models import gloria_model as GM
+    from gloria.trainer import Trainer
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    for k, v in dict(GLR_FORCE_DIST="1", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+                     MASTER_PORT=str(port)).items():
+        monkeypatch.setenv(k, v)
+    keep = GM.ENCODER_STREAMS
+    try:
+        dctx = gdist.init_from_env("nccl")
+        GM.ENCODER_STREAMS = streams
+        cfg = pretrain_config("imagenome", batch_size=B)
+        torch.manual_seed(31)
+        model = builder.build_lightning_model(cfg, builder.build_data_module(cfg))
+        tr = Trainer(cfg, device="cuda:0", precision="bf16", dist_ctx=dctx)
+        tr.setup(model)
+        model.train()
+        batch = make_batch(B, seed=8, lengths="words")
+        torch.manual_seed(17)
+        torch.cuda.manual_seed(17)
+        losses = []
+        for step in range(4):
+            losses.append(float(tr.training_step(model, batch, step)))
+            torch.cuda.synchronize()
+            _check_clip(tr)
+            for g in tr.optimizer.groups:
+                assert torch.isfinite(g.grad.float()).all()
+        assert model.gloria._img_graph is not None and model.gloria.text_encoder._graph is not None
+        assert losses[1] < losses[0] - 0.5 and losses[3] < losses[0] - 3.0, losses      # 21.66 -> 20.0 -> 17.4 -> ~15
+    finally:
+        GM.ENCODER_STREAMS = keep
+        if dist.is_initialized():
+            dist.destroy_process_group()
 
 
 def test_graphed_text_encoder_equals_eager():

@@ -6,6 +6,7 @@ ROOT=$(pwd)
 OUT="$ROOT/gpurun_out/$TAG"
 mkdir -p "$OUT"
 say() { echo "[collect] $*"; }
+say "ablation library"; make -C gloria-nlp-project_amd/csrc ablate > "$OUT/make_ablate.log" 2>&1
 say "bench default"; timeout -k 10 500 python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"
 say "bench max lengths"; timeout -k 10 300 python bench.py --lengths max --no-cpu-baseline --steps 5 > "$OUT/bench_max_lengths.json" 2>> "$OUT/bench.err"
 say "bench cfg2 fp32 B=64"; timeout -k 10 300 python bench.py --precision fp32 --global-batch 64 --no-cpu-baseline --steps 5 > "$OUT/bench_cfg2_fp32_b64.json" 2>> "$OUT/bench.err"
