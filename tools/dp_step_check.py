@@ -41,7 +41,7 @@ if tr.reducer is not None and os.environ.get("DBG_FINISH"):
     tr.reducer.finish = finish
 torch.manual_seed(17); torch.cuda.manual_seed(17)
 names = {id(p): n for n, p in model.named_parameters()}
-for step in range(3):
+for step in range(int(os.environ.get("STEPS", "3"))):
     loss = float(tr.training_step(model, batch, step))
     torch.cuda.synchronize()
     bad = []
