@@ -347,6 +347,41 @@ def test_properties_b256(dtype):
     assert torch.isfinite(l0) and torch.isfinite(l1)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_b256_rows_vs_oracle(dtype):
+    """The bench shape itself (256 x 256 pairs, 19 x 19 regions, the metric's caption lengths: the `k_local_attn_t1`
+    launch of 24 064 workgroups and the pair backward) against the oracle, forward AND backward: sim[b, i] depends on
+    image b and sentence i only, so the oracle evaluates 24 image rows spread over the batch against ALL 256 sentences
+    (a sixteenth of the full CPU cost) and the loss of the comparison touches exactly those rows."""
+    img, words, lens = _bench_inputs()
+    rows = torch.tensor(sorted({0, 1, 7, 31, 32, 63, 64, 65, 100, 127, 128, 129, 160, 191, 192, 200, 222, 240, 254, 255, 17, 45, 90, 140}))
+    assert len(rows) == 24
+    ti = img.to(dtype).requires_grad_(True)
+    tw = words.to(dtype).requires_grad_(True)
+    sim, _, _ = gl().local_similarity(ti, tw, lens, want_attn=False)
+    ri = ti.detach()[rows.to(DEV)].float().cpu().requires_grad_(True)
+    rw = tw.detach().float().cpu().requires_grad_(True)
+    want = orc().local_similarity_matrix(ri, rw, lens)
+    got = sim[rows.to(DEV)].detach().float().cpu()
+    err = (got - want.detach()).abs().max().item()
+    print(f"[{dtype} B=256 rows] max |sim - oracle| = {err:.5f}")
+    assert err < (BF16_SIM_ATOL if dtype == torch.bfloat16 else 2e-3), err
+    gsim = torch.from_numpy(gi.normal(991, *want.shape, std=1.0))
+    weight = torch.zeros(sim.shape, dtype=torch.float32)
+    weight[rows] = gsim
+    (sim.float() * weight.to(DEV)).sum().backward()
+    (want * gsim).sum().backward()
+    tol = BF16_GRAD_REL if dtype == torch.bfloat16 else 2e-4
+    for label, a, b in (("img rows", ti.grad[rows.to(DEV)], ri.grad), ("words", tw.grad, rw.grad)):
+        a, b = a.float().cpu().numpy(), b.numpy()
+        rel = np.linalg.norm(a - b) / np.linalg.norm(b)
+        print(f"[{dtype} B=256 rows] grad {label}: relative Frobenius error {rel:.5f}")
+        assert rel < tol, (label, rel)
+    others = torch.ones(256, dtype=torch.bool)
+    others[rows] = False
+    assert float(ti.grad[others.to(DEV)].abs().max()) == 0.0          # images outside the loss get exactly zero
+
+
 def test_dual_ce_matches_torch():
     sim = torch.randn(256, 256, device=DEV, generator=torch.Generator(DEV).manual_seed(5)) * 8
     a = sim.clone().requires_grad_(True)
