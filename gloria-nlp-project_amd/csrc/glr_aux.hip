@@ -312,7 +312,118 @@ __global__ void __launch_bounds__(256) k_attn_reg_bwd(const float* __restrict__ 
   }
 }
 
+// ------------------------------------------------------------------ embedding-table gradients (BertEmbeddings)
+// torch's embedding_dense_backward sorts the indices on the device and runs ~17 launches per table; its
+// `sum_and_scatter` takes 0.4 - 0.6 ms per table at 24 832 tokens because one token id ([PAD], or the single token type)
+// owns most rows.  Here the WORD table's segments come from the host (the trainer keeps the caption ids on the host
+// anyway: a stable argsort, padding rows dropped): one workgroup per distinct token sums that token's rows in the fixed
+// order of the sort - D / 4 column threads x 4 row lanes, four loads in flight per lane, lanes combined in order.  The
+// TOKEN-TYPE table has two rows: both are masked column sums of dy (two-level, fixed order), out[0] = all - out[1].
+constexpr int EMB_LANES = 4;
+__global__ void __launch_bounds__(1024) k_embedding_bwd(const float* __restrict__ dy, const int* __restrict__ order,
+                                                        const int* __restrict__ seg_lo, const int* __restrict__ seg_hi,
+                                                        const int* __restrict__ seg_tok, int D, float* __restrict__ dW) {
+  extern __shared__ float4 emb_red[];               // [EMB_LANES][D / 4]
+  const int nc = D / 4, ct = threadIdx.x % nc, rl = threadIdx.x / nc;
+  const int u = blockIdx.x, k0 = seg_lo[u], k1 = seg_hi[u];
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  int k = k0 + rl;
+  for (; k + 3 * EMB_LANES < k1; k += 4 * EMB_LANES) {
+    float4 v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = *reinterpret_cast<const float4*>(dy + (size_t)order[k + j * EMB_LANES] * D + 4 * ct);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { acc.x += v[j].x; acc.y += v[j].y; acc.z += v[j].z; acc.w += v[j].w; }
+  }
+  for (; k < k1; k += EMB_LANES) {
+    const float4 v = *reinterpret_cast<const float4*>(dy + (size_t)order[k] * D + 4 * ct);
+    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+  }
+  emb_red[rl * nc + ct] = acc;
+  __syncthreads();
+  if (rl == 0) {
+    float4 s = emb_red[ct];
+#pragma unroll
+    for (int j = 1; j < EMB_LANES; ++j) {
+      const float4 t = emb_red[j * nc + ct];
+      s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+    }
+    *reinterpret_cast<float4*>(dW + (size_t)seg_tok[u] * D + 4 * ct) = s;
+  }
+}
+
+constexpr int TE_COLS = 256;                         // columns per workgroup: 64 threads x float4
+__global__ void __launch_bounds__(256) k_type_emb_partial(const float* __restrict__ dy, const long long* __restrict__ tt, long long R,
+                                                          int D, long long rows_per, float* __restrict__ part) {
+  const int ct = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int col0 = blockIdx.x * TE_COLS + 4 * ct;
+  const long long r0 = (long long)blockIdx.y * rows_per, r1 = r0 + rows_per < R ? r0 + rows_per : R;
+  float4 all = make_float4(0.f, 0.f, 0.f, 0.f), one = all;
+  for (long long r = r0 + rl; r < r1; r += 4) {
+    const float4 v = *reinterpret_cast<const float4*>(dy + r * D + col0);
+    const float m = tt[r] != 0 ? 1.f : 0.f;
+    all.x += v.x; all.y += v.y; all.z += v.z; all.w += v.w;
+    one.x += m * v.x; one.y += m * v.y; one.z += m * v.z; one.w += m * v.w;
+  }
+  __shared__ float4 red[2][4][64];
+  red[0][rl][ct] = all;
+  red[1][rl][ct] = one;
+  __syncthreads();
+  if (rl < 2) {                                     // wave 0: class "all", wave 1: class "one"
+    float4 s = red[rl][0][ct];
+#pragma unroll
+    for (int j = 1; j < 4; ++j) { const float4 t = red[rl][j][ct]; s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w; }
+    const float sv[4] = {s.x, s.y, s.z, s.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) part[((size_t)rl * D + col0 + i) * gridDim.y + blockIdx.y] = sv[i];
+  }
+}
+__global__ void __launch_bounds__(256) k_type_emb_finish(const float* __restrict__ part, int n_part, int D, float* __restrict__ dW2) {
+  const int lane = threadIdx.x & 63;
+  const int col = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (col >= D) return;
+  float a = 0.f, o = 0.f;
+  for (int k = lane; k < n_part; k += 64) { a += part[(size_t)col * n_part + k]; o += part[((size_t)D + col) * n_part + k]; }
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) { a += __shfl_xor(a, m, 64); o += __shfl_xor(o, m, 64); }
+  if (lane == 0) { dW2[col] = a - o; dW2[D + col] = o; }
+}
+int type_emb_parts(long long R, int D) {
+  long long np = 1024 / (D / TE_COLS);
+  const long long mx = (R + 15) / 16;
+  if (np > mx) np = mx;
+  return (int)(np < 1 ? 1 : np);
+}
+
 }  // namespace
+
+extern "C" int glr_embedding_bwd(const float* dy, const int32_t* order, const int32_t* seg_lo, const int32_t* seg_hi,
+                                 const int32_t* seg_tok, int n_seg, int D, float* dW, void* stream) {
+  if (!dy || !order || !seg_lo || !seg_hi || !seg_tok || !dW || n_seg < 0 || D <= 0 || D % 4 != 0 || D > 1024) return GLR_EINVAL;
+  if (n_seg == 0) return GLR_OK;
+  const int nc = D / 4;
+  hipLaunchKernelGGL(k_embedding_bwd, dim3(n_seg), dim3(nc * EMB_LANES), (size_t)EMB_LANES * nc * sizeof(float4), (hipStream_t)stream,
+                     dy, order, seg_lo, seg_hi, seg_tok, D, dW);
+  GLR_CHECK_LAUNCH();
+  return GLR_OK;
+}
+
+extern "C" int glr_type_embedding_workspace_floats(long long R, int D) {
+  return (R > 0 && D >= TE_COLS && D % TE_COLS == 0) ? 2 * D * type_emb_parts(R, D) : 0;
+}
+
+extern "C" int glr_type_embedding_bwd(const float* dy, const int64_t* token_type, long long R, int D, float* workspace, float* dW2,
+                                      void* stream) {
+  if (!dy || !token_type || !workspace || !dW2 || R <= 0 || D < TE_COLS || D % TE_COLS != 0) return GLR_EINVAL;
+  const int np = type_emb_parts(R, D);
+  const long long rows_per = (R + np - 1) / np;
+  hipLaunchKernelGGL(k_type_emb_partial, dim3(D / TE_COLS, np), dim3(256), 0, (hipStream_t)stream, dy, (const long long*)token_type, R, D,
+                     rows_per, workspace);
+  GLR_CHECK_LAUNCH();
+  hipLaunchKernelGGL(k_type_emb_finish, dim3((D + 3) / 4), dim3(256), 0, (hipStream_t)stream, workspace, np, D, dW2);
+  GLR_CHECK_LAUNCH();
+  return GLR_OK;
+}
 
 extern "C" int glr_attn_reg_fwd(const float* amean, int B_img, int n_sent, int S_pad, int S_eff, int shift,
                                 int img_offset, float* out, void* stream) {

@@ -64,6 +64,9 @@ SYMBOLS = {
                                     c_void_p]),
     "glr_drop_add_ln_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_longlong,
                                     c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "glr_embedding_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "glr_type_embedding_workspace_floats": (c_int, [ctypes.c_longlong, c_int]),
+    "glr_type_embedding_bwd": (c_int, [c_void_p, c_void_p, ctypes.c_longlong, c_int, c_void_p, c_void_p, c_void_p]),
     "glr_colsum_workspace_floats": (c_int, [ctypes.c_longlong, c_int]),
     "glr_colsum_bf16": (c_int, [c_void_p, ctypes.c_longlong, c_int, c_void_p, c_void_p, c_int, c_void_p]),
     "glr_attn_max_tokens": (c_int, [c_int]),

@@ -9,6 +9,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .fused_attn import packed_fusable, self_attention, self_attention_packed
+from .fused_embed import type_embedding, word_embedding
 from .fused_linear import linear
 from .fused_ln import dense_drop_add_ln
 
@@ -41,7 +42,9 @@ class BertEmbeddings(nn.Module):
             token_type = torch.zeros_like(ids)
         # positions are arange(L) (position_ids[:, :L]): the first L rows of the table, broadcast over the batch - the
         # backward is then a plain sum over the batch instead of the sort-and-scatter of an embedding lookup (0.55 ms)
-        x = self.word_embeddings(ids) + self.token_type_embeddings(token_type) + self.position_embeddings.weight[:L]
+        # the two lookups keep torch's gather; their table gradients skip torch's device sort (models/fused_embed.py)
+        x = word_embedding(self.word_embeddings, ids) + type_embedding(self.token_type_embeddings, token_type) \
+            + self.position_embeddings.weight[:L]
         return self.dropout(self.LayerNorm(x))
 
 

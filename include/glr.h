@@ -403,6 +403,18 @@ int glr_drop_add_ln_bwd(const float* dy32, const void* dy16, const void* h16, co
                         const float* stats, const unsigned long long* mask, long long R, int H, float p_drop,
                         float* d_inp32, void* d_h16, float* workspace, float* dgamma, float* dbeta, void* dhsum, int dhsum_bf16,
                         void* stream);
+/* Gradients of BertEmbeddings' lookup tables (torch: embedding_dense_backward, a device sort + ~17 launches per table).
+ *   glr_embedding_bwd       dW[seg_tok[u], :] = sum over k in [seg_lo[u], seg_hi[u]) of dy[order[k], :], rows added in that
+ *                           order (fp32 [tokens, D] in, fp32 table out; rows of no segment keep what dW holds: pass zeros).
+ *                           order / seg_*: the HOST's stable argsort of the token ids and its runs (padding run left out).
+ *   glr_type_embedding_bwd  two-row table: dW2[1] = sum of dy rows with token_type != 0, dW2[0] = the others (two-level
+ *                           fixed-order sums); workspace glr_type_embedding_workspace_floats(R, D) floats, D % 256 == 0.
+ */
+int glr_embedding_bwd(const float* dy, const int32_t* order, const int32_t* seg_lo, const int32_t* seg_hi, const int32_t* seg_tok,
+                      int n_seg, int D, float* dW, void* stream);
+int glr_type_embedding_workspace_floats(long long R, int D);
+int glr_type_embedding_bwd(const float* dy, const int64_t* token_type, long long R, int D, float* workspace, float* dW2,
+                           void* stream);
 int glr_colsum_workspace_floats(long long R, int C);
 int glr_colsum_bf16(const void* x16, long long R, int C, float* workspace, void* out, int out_bf16, void* stream);
 

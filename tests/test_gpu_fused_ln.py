@@ -205,3 +205,46 @@ def test_bert_bf16_parameter_linears_match_autograd(monkeypatch):
         np.testing.assert_allclose(got[n].cpu().numpy() / scale, ref[n].cpu().numpy() / scale, atol=tol, err_msg=n)
         n_bias += n.endswith("dense.bias") or n.endswith("query.bias")
     assert n_bias >= 8
+
+
+def test_embedding_table_gradients_match_torch():
+    """glr_embedding_bwd (host-sorted segments, padding rows dropped) and glr_type_embedding_bwd (two masked column sums)
+    against torch's embedding backward on BertEmbeddings: the SAME fp32 values summed in a different order"""
+    from gloria.models import bert as B
+    from gloria.models import fused_embed as FE
+    torch.manual_seed(0)
+    cfg = B.BertConfig(vocab_size=500, hidden_size=768, num_hidden_layers=1, num_attention_heads=12, intermediate_size=256,
+                       hidden_dropout_prob=0.0)
+    emb = B.BertEmbeddings(cfg).to(DEV).train()
+    Bn, L = 64, 97
+    ids = torch.randint(1, 500, (Bn, L))
+    ids[:, 0] = 2                                    # [CLS]-like: one long segment
+    ids[:, 40:] = 0                                  # padding id: most rows, no gradient
+    ids[5, 3] = 499
+    tt = torch.zeros(Bn, L, dtype=torch.int64)
+    tt[::3, 10:20] = 1
+    proj = torch.randn(Bn, L, 768, device=DEV)
+
+    def run(fused, host):
+        FE.ENABLED = fused
+        d_ids = ids.to(DEV)
+        if host:
+            d_ids._glr_host = ids.numpy()
+        emb.zero_grad(set_to_none=True)
+        (emb(d_ids, tt.to(DEV)) * proj).sum().backward()
+        return {n: p.grad.clone() for n, p in emb.named_parameters()}
+    try:
+        ref = run(False, False)
+        got = run(True, True)
+        nohost = run(True, False)                    # word table falls back to torch, the type table stays fused
+    finally:
+        FE.ENABLED = True
+    assert set(ref) == set(got)
+    for n in ref:
+        scale = float(ref[n].abs().max())
+        np.testing.assert_allclose(got[n].cpu().numpy() / scale, ref[n].cpu().numpy() / scale, atol=2e-6, err_msg=n)
+        np.testing.assert_allclose(nohost[n].cpu().numpy() / scale, ref[n].cpu().numpy() / scale, atol=2e-6, err_msg=n)
+    assert float(got["word_embeddings.weight"][0].abs().max()) == 0.0           # padding_idx row
+    assert float(got["word_embeddings.weight"][499].abs().max()) > 0.0
+    again = run(True, True)
+    assert all(torch.equal(again[n], got[n]) for n in got)                       # fixed summation order: bitwise repeatable
