@@ -113,12 +113,12 @@ class GLoRIA(nn.Module):
 
     def enable_image_graph(self, sample_imgs, autocast_dtype=None, warmup=3):
         """Capture the image encoder's forward AND backward (static shapes, no dropout, no data-dependent allocation:
-        ~500 of the step's ~1150 launches) into two hipGraphs (torch.cuda.make_graphed_callables).  The 32-pair
-        data-parallel step is bound by HOST time; a replay costs the host two launches, and with the text encoder on its
-        side stream the host queues BERT while the device replays the image graph.  The text encoder stays eager: its
-        embedding backward replays with capture-time sizes (round 1's aperture violation), and its dropout keys come
-        from the host.  BatchNorm buffers are restored after the warm-up passes, so the first real step sees the
-        statistics an eager run would."""
+        ~500 of the step's ~1100 launches) into two hipGraphs (torch.cuda.make_graphed_callables).  Small per-rank batches
+        are bound by the HOST time of these launches; a replay costs the host two.  The text encoder's layers are captured
+        the same way by `enable_text_graph`.  Refused unless the HIP runtime's graph packet capture is off (gloria/hipgraph.py:
+        it races with MIOpen's memset nodes), and verified against an eager pass before it is used.  BatchNorm buffers are
+        restored after the capture's warm-up / verification passes, so the first real step sees the statistics an eager
+        run would."""
         from .. import hipgraph
         if not sample_imgs.is_cuda or self.position_embeddings is not None or self.image_transformer is not None:
             return False
