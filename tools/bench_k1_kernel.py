@@ -22,17 +22,20 @@ if mode == "max":
     lens = [96] * B
 else:   # the bench's captions: word counts U{4..39} + [CLS]
     lens = sorted((int(x) + 1 for x in np.random.default_rng(1234).integers(4, 40, size=B)), reverse=True)
+TRAIN = os.environ.get("TRAIN", "0") == "1"       # as inside a training step: a1 handed to the backward, attention maps written
+if TRAIN:
+    img.requires_grad_(True); words.requires_grad_(True)
 for _ in range(3):
-    gl.local_similarity(img, words, lens, want_attn=False, no_attn_vec=na)
+    gl.local_similarity(img, words, lens, want_attn=TRAIN, no_attn_vec=na)
 torch.cuda.synchronize()
 gl.PROFILE = {}
 for _ in range(iters):
-    gl.local_similarity(img, words, lens, want_attn=False, no_attn_vec=na)
+    gl.local_similarity(img, words, lens, want_attn=TRAIN, no_attn_vec=na)
 torch.cuda.synchronize()
 prof, gl.PROFILE = gl.PROFILE, None
 ms = lambda k: sorted(a.elapsed_time(b) for a, b in prof[k])
 k, o = ms("k1_fwd"), ms("k1_fwd_op")
 fl = prof["k1_flops"][0]
-print(f"B={B} {mode} sum(cap_lens)={sum(lens)} T1={os.environ.get('GLR_K1_T1', '1')} IB={os.environ.get('GLR_K1_IMG_BLOCK', '-')}: "
+print(f"TRAIN={int(TRAIN)} B={B} {mode} sum(cap_lens)={sum(lens)} T1={os.environ.get('GLR_K1_T1', '1')} IB={os.environ.get('GLR_K1_IMG_BLOCK', '-')}: "
       f"kernel median {k[len(k)//2]:.3f} ms (min {k[0]:.3f}) = {fl / k[len(k)//2] / 1e9:.0f} TFLOP/s = {fl / k[len(k)//2] / 1e9 / 2500:.3f} of peak; "
       f"op median {o[len(o)//2]:.3f} ms = {fl / o[len(o)//2] / 1e9 / 2500:.3f}", flush=True)
