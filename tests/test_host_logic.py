@@ -1,6 +1,8 @@
 """CPU tests of the host-side mirror: config semantics, word-piece slotting (against the reference's
 outputs in tests/golden/text.npz), builder/optimizer wiring, checkpoint key layout."""
 
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -256,3 +258,30 @@ def test_chexpert_pretrain_config_builds_and_steps_on_cpu():
     assert torch.isfinite(loss) and len(maps) == 4
     opt = model.configure_optimizers()["optimizer"]
     assert opt.param_groups[0]["betas"] == (0.5, 0.999) and abs(opt.param_groups[0]["lr"] - 5e-5) < 1e-12
+
+
+def test_hipgraph_gate_and_consistency_check(monkeypatch):
+    """gloria/hipgraph.py on the CPU: the runtime flag is put in the environment (and graphs are refused when the user
+    forces packet capture on), and the replay check flags NaN / drifted replays"""
+    import importlib
+    import warnings
+    import torch
+    from gloria import hipgraph
+    assert os.environ.get(hipgraph.ENV) == "0" and hipgraph.SAFE          # conftest / package import put it there
+    monkeypatch.setenv(hipgraph.ENV, "1")
+    assert importlib.reload(hipgraph).SAFE is False
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        assert hipgraph.usable("image encoder") is False and "runs eagerly" in str(w[-1].message)
+    monkeypatch.delenv(hipgraph.ENV)
+    assert importlib.reload(hipgraph).SAFE is True and os.environ[hipgraph.ENV] == "0"      # CPU box: torch.cuda never initialised
+    ref = [torch.arange(6.0).reshape(2, 3), torch.ones(4)]
+    good = [t.clone() for t in ref]
+    near = [t * 1.01 for t in ref]
+    bad = [ref[0].clone(), torch.tensor([1.0, float("nan"), 1.0, 1.0])]
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        assert hipgraph.consistent("x", ref, [good, near])
+        assert not hipgraph.consistent("x", ref, [good, bad]) and "differs from the eager pass" in str(w[-1].message)
+        assert not hipgraph.consistent("x", ref, [[t * 2 for t in ref]])
+        assert not hipgraph.consistent("x", [torch.zeros(3)], [[torch.zeros(3)]])       # no signal to compare against
