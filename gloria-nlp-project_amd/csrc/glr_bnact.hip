@@ -41,17 +41,40 @@ __device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
 __device__ __forceinline__ uint4 ldv(const unsigned short* p) { return *reinterpret_cast<const uint4*>(p); }
 __device__ __forceinline__ void stv(unsigned short* p, uint4 v) { *reinterpret_cast<uint4*>(p) = v; }
 
+// eight consecutive channels of one row, by element type: bf16 (16 bytes, the training configuration) or fp32 (32 bytes,
+// the fp32 parity configuration of BASELINE config 1; round 3).  UNROLL scales the independent loads per thread so that
+// the bytes in flight (and the registers holding them) are the same for both.
+template <typename E> struct Vec8;
+template <> struct Vec8<unsigned short> { uint4 v; };
+template <> struct Vec8<float> { float4 a, b; };
+template <typename E> struct ElemTraits;
+template <> struct ElemTraits<unsigned short> { static constexpr int SHIFT = 0; };
+template <> struct ElemTraits<float> { static constexpr int SHIFT = 1; };
+__device__ __forceinline__ Vec8<unsigned short> ld8(const unsigned short* p) { return {ldv(p)}; }
+__device__ __forceinline__ Vec8<float> ld8(const float* p) {
+  return {*reinterpret_cast<const float4*>(p), *reinterpret_cast<const float4*>(p + 4)};
+}
+__device__ __forceinline__ void un8(const Vec8<unsigned short>& v, float (&f)[8]) { unpack8(v.v, f); }
+__device__ __forceinline__ void un8(const Vec8<float>& v, float (&f)[8]) {
+  f[0] = v.a.x; f[1] = v.a.y; f[2] = v.a.z; f[3] = v.a.w; f[4] = v.b.x; f[5] = v.b.y; f[6] = v.b.z; f[7] = v.b.w;
+}
+__device__ __forceinline__ void st8(unsigned short* p, const float (&f)[8]) { stv(p, pack8(f)); }
+__device__ __forceinline__ void st8(float* p, const float (&f)[8]) {
+  *reinterpret_cast<float4*>(p) = make_float4(f[0], f[1], f[2], f[3]);
+  *reinterpret_cast<float4*>(p + 4) = make_float4(f[4], f[5], f[6], f[7]);
+}
+
 // ---- pass 1 of both directions: per-channel partial sums of two quantities over a slab of rows
 //   MODE 0 (forward stats)  q0 = x,  q1 = x^2
 //   MODE 1 (backward)       q0 = dz, q1 = dz * xhat,  dz = dy * [z > 0]   (RESID: mask from y, dz also written out)
-template <int MODE, bool RESID>
-__global__ void __launch_bounds__(BN_NT) k_bn_reduce(const unsigned short* __restrict__ x, const unsigned short* __restrict__ dy,
-                                                     const unsigned short* __restrict__ y, const float* __restrict__ mean,
+template <typename E, int MODE, bool RESID>
+__global__ void __launch_bounds__(BN_NT) k_bn_reduce(const E* __restrict__ x, const E* __restrict__ dy,
+                                                     const E* __restrict__ y, const float* __restrict__ mean,
                                                      const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, long long R, int C, int relu,
                                                      int n_part, float* __restrict__ part,
-                                                     unsigned short* __restrict__ dz_out, const unsigned short* __restrict__ dy2) {
-  constexpr int UN = MODE == 0 ? 8 : 4;
+                                                     E* __restrict__ dz_out, const E* __restrict__ dy2) {
+  constexpr int UN = (MODE == 0 ? 8 : 4) >> ElemTraits<E>::SHIFT;
   const int cg_per_blk = min(C / 8, 32), rl_per_blk = BN_NT / cg_per_blk;
   const int cg = blockIdx.x * cg_per_blk + threadIdx.x % cg_per_blk, rl = threadIdx.x / cg_per_blk;
   const int c0 = cg * 8;
@@ -70,16 +93,16 @@ __global__ void __launch_bounds__(BN_NT) k_bn_reduce(const unsigned short* __res
   const long long r_end = R;
   const long long slab = (long long)UN * rl_per_blk;
   for (long long r = (long long)blockIdx.y * slab + rl; r < r_end; r += slab * gridDim.y) {
-    uint4 xr[UN], dr[UN], yr[UN], d2[UN];
+    Vec8<E> xr[UN], dr[UN], yr[UN], d2[UN];
     const bool two = MODE == 1 && RESID && dy2 != nullptr;     // the gradient arrives as two tensors (main + skip consumer)
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
       const long long ru = r + (long long)u * rl_per_blk;
       if (ru < r_end) {
-        xr[u] = ldv(x + ru * C + c0);
-        if (MODE == 1) dr[u] = ldv(dy + ru * C + c0);
-        if (MODE == 1 && RESID) yr[u] = ldv(y + ru * C + c0);
-        if (two) d2[u] = ldv(dy2 + ru * C + c0);
+        xr[u] = ld8(x + ru * C + c0);
+        if (MODE == 1) dr[u] = ld8(dy + ru * C + c0);
+        if (MODE == 1 && RESID) yr[u] = ld8(y + ru * C + c0);
+        if (two) d2[u] = ld8(dy2 + ru * C + c0);
       }
     }
 #pragma unroll
@@ -87,17 +110,17 @@ __global__ void __launch_bounds__(BN_NT) k_bn_reduce(const unsigned short* __res
       const long long ru = r + (long long)u * rl_per_blk;
       if (ru < r_end) {
         float xv[8];
-        unpack8(xr[u], xv);
+        un8(xr[u], xv);
         if (MODE == 0) {
 #pragma unroll
           for (int i = 0; i < 8; ++i) { a0[i] += xv[i]; a1[i] = __builtin_fmaf(xv[i], xv[i], a1[i]); }
         } else {
           float dv[8], yv[8], dzv[8];
-          unpack8(dr[u], dv);
-          if (RESID) unpack8(yr[u], yv);
+          un8(dr[u], dv);
+          if (RESID) un8(yr[u], yv);
           if (two) {
             float d2v[8];
-            unpack8(d2[u], d2v);
+            un8(d2[u], d2v);
 #pragma unroll
             for (int i = 0; i < 8; ++i) dv[i] += d2v[i];
           }
@@ -109,7 +132,7 @@ __global__ void __launch_bounds__(BN_NT) k_bn_reduce(const unsigned short* __res
             a0[i] += dz;
             a1[i] = __builtin_fmaf(dz, (xv[i] - mu[i]) * is[i], a1[i]);
           }
-          if (RESID) stv(dz_out + ru * C + c0, pack8(dzv));
+          if (RESID) st8(dz_out + ru * C + c0, dzv);
         }
       }
     }
@@ -175,22 +198,22 @@ __global__ void __launch_bounds__(BN_NT) k_bn_finish(const float* __restrict__ p
 }
 
 // forward apply: y = relu?( (x - mean) invstd gamma + beta (+ residual) ); blocks walk the tensor backwards
-template <bool RESID>
-__global__ void __launch_bounds__(BN_NT) k_bn_apply(const unsigned short* __restrict__ x, const unsigned short* __restrict__ res,
+template <typename E, bool RESID>
+__global__ void __launch_bounds__(BN_NT) k_bn_apply(const E* __restrict__ x, const E* __restrict__ res,
                                                     const float* __restrict__ mean, const float* __restrict__ invstd,
                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                    long long n_vec, int C, int relu, unsigned short* __restrict__ y) {
-  constexpr int UN = 4;
+                                                    long long n_vec, int C, int relu, E* __restrict__ y) {
+  constexpr int UN = 4 >> ElemTraits<E>::SHIFT;
   const unsigned cpr = (unsigned)C / 8u;                     // a power of two <= 256: a thread keeps its channels
   const int c0 = (int)(threadIdx.x & (cpr - 1)) * 8;
   const long long v0 = (long long)(gridDim.x - 1 - blockIdx.x) * (BN_NT * UN) + threadIdx.x;
-  uint4 xr[UN], rr[UN];
+  Vec8<E> xr[UN], rr[UN];
 #pragma unroll
   for (int u = 0; u < UN; ++u) {
     const long long v = v0 + u * BN_NT;
     if (v < n_vec) {
-      xr[u] = ldv(x + v * 8);
-      if (RESID) rr[u] = ldv(res + v * 8);
+      xr[u] = ld8(x + v * 8);
+      if (RESID) rr[u] = ld8(res + v * 8);
     }
   }
   float sc[8], sh[8];
@@ -204,37 +227,37 @@ __global__ void __launch_bounds__(BN_NT) k_bn_apply(const unsigned short* __rest
     const long long v = v0 + u * BN_NT;
     if (v < n_vec) {
       float xv[8], rv[8], o[8];
-      unpack8(xr[u], xv);
-      if (RESID) unpack8(rr[u], rv);
+      un8(xr[u], xv);
+      if (RESID) un8(rr[u], rv);
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         float z = __builtin_fmaf(xv[i], sc[i], sh[i]);
         if (RESID) z += rv[i];
         o[i] = relu ? fmaxf(z, 0.f) : z;
       }
-      stv(y + v * 8, pack8(o));
+      st8(y + v * 8, o);
     }
   }
 }
 
 // backward apply: dx = (dz - mean(dz) - xhat mean(dz xhat)) invstd gamma.  RESID: `dy` is the dz the reduce pass wrote.
-template <bool RESID>
-__global__ void __launch_bounds__(BN_NT) k_bn_bwd_apply(const unsigned short* __restrict__ x, const unsigned short* __restrict__ dy,
+template <typename E, bool RESID>
+__global__ void __launch_bounds__(BN_NT) k_bn_bwd_apply(const E* __restrict__ x, const E* __restrict__ dy,
                                                         const float* __restrict__ mean, const float* __restrict__ invstd,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         const float* __restrict__ m_dz, const float* __restrict__ m_dzx,
-                                                        long long n_vec, int C, int relu, unsigned short* __restrict__ dx) {
-  constexpr int UN = 4;
+                                                        long long n_vec, int C, int relu, E* __restrict__ dx) {
+  constexpr int UN = 4 >> ElemTraits<E>::SHIFT;
   const unsigned cpr = (unsigned)C / 8u;
   const int c0 = (int)(threadIdx.x & (cpr - 1)) * 8;
   const long long v0 = (long long)(gridDim.x - 1 - blockIdx.x) * (BN_NT * UN) + threadIdx.x;
-  uint4 xr[UN], dr[UN];
+  Vec8<E> xr[UN], dr[UN];
 #pragma unroll
   for (int u = 0; u < UN; ++u) {
     const long long v = v0 + u * BN_NT;
     if (v < n_vec) {
-      xr[u] = ldv(x + v * 8);
-      dr[u] = ldv(dy + v * 8);
+      xr[u] = ld8(x + v * 8);
+      dr[u] = ld8(dy + v * 8);
     }
   }
   // dx = dz * k1 - (k2 + x * k3):  k1 = invstd gamma, k3 = invstd mean(dz xhat) k1, k2 = mean(dz) k1 - mean k3
@@ -252,15 +275,15 @@ __global__ void __launch_bounds__(BN_NT) k_bn_bwd_apply(const unsigned short* __
     const long long v = v0 + u * BN_NT;
     if (v < n_vec) {
       float xv[8], dv[8], o[8];
-      unpack8(xr[u], xv);
-      unpack8(dr[u], dv);
+      un8(xr[u], xv);
+      un8(dr[u], dv);
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const bool on = RESID || !relu || __builtin_fmaf(xv[i], k1[i], sh[i]) > 0.f;
         const float dz = on ? dv[i] : 0.f;
         o[i] = __builtin_fmaf(dz, k1[i], -__builtin_fmaf(xv[i], k3[i], k2[i]));
       }
-      stv(dx + v * 8, pack8(o));
+      st8(dx + v * 8, o);
     }
   }
 }
@@ -297,68 +320,96 @@ extern "C" int glr_bn_workspace_floats(long long R, int C) {
   return bn_plan(R, C, BN_MAX_WG, 1).n_part * 2 * C;          // upper bound over both directions
 }
 
-extern "C" int glr_bn_act_fwd(const void* x, const void* residual, const float* gamma, const float* beta, long long R,
-                              int C, float eps, float momentum, int relu, float* run_mean, float* run_var,
-                              long long* num_batches_tracked, float* mean, float* invstd, float* workspace, void* y,
-                              void* stream) {
-  if (!x || !gamma || !beta || !mean || !invstd || !workspace || !y || !bn_shape_ok(R, C)) return GLR_EINVAL;
-  hipStream_t st = (hipStream_t)stream;
+template <typename E>
+int bn_fwd_launch(const void* x, const void* residual, const float* gamma, const float* beta, long long R, int C, float eps,
+                  float momentum, int relu, float* run_mean, float* run_var, long long* num_batches_tracked, float* mean,
+                  float* invstd, float* workspace, void* y, hipStream_t st) {
+  constexpr int UNA = 4 >> ElemTraits<E>::SHIFT;
   static GlrOccupancy occ0;
-  const int res0 = bn_resident(occ0, (const void*)k_bn_reduce<0, false>);
-  const BnPlan pl = bn_plan(R, C, res0, 8);
-  hipLaunchKernelGGL((k_bn_reduce<0, false>), dim3(pl.col_blocks, pl.n_part), dim3(BN_NT), 0, st, (const unsigned short*)x,
-                     nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, R, C, 0, pl.n_part, workspace, nullptr, nullptr);
+  const int res0 = bn_resident(occ0, (const void*)k_bn_reduce<E, 0, false>);
+  const BnPlan pl = bn_plan(R, C, res0, 8 >> ElemTraits<E>::SHIFT);
+  hipLaunchKernelGGL((k_bn_reduce<E, 0, false>), dim3(pl.col_blocks, pl.n_part), dim3(BN_NT), 0, st, (const E*)x,
+                     (const E*)nullptr, (const E*)nullptr, nullptr, nullptr, nullptr, nullptr, R, C, 0, pl.n_part, workspace,
+                     (E*)nullptr, (const E*)nullptr);
   GLR_CHECK_LAUNCH();
   hipLaunchKernelGGL((k_bn_finish<true>), dim3((C + 3) / 4), dim3(BN_NT), 0, st, workspace, pl.n_part, C, R, eps, momentum,
                      mean, invstd, run_mean, run_var, num_batches_tracked);
   GLR_CHECK_LAUNCH();
   const long long n_vec = R * C / 8;
-  const int grid = (int)((n_vec + BN_NT * 4 - 1) / (BN_NT * 4));
+  const int grid = (int)((n_vec + BN_NT * UNA - 1) / (BN_NT * UNA));
   if (residual)
-    hipLaunchKernelGGL((k_bn_apply<true>), dim3(grid), dim3(BN_NT), 0, st, (const unsigned short*)x, (const unsigned short*)residual,
-                       mean, invstd, gamma, beta, n_vec, C, relu, (unsigned short*)y);
+    hipLaunchKernelGGL((k_bn_apply<E, true>), dim3(grid), dim3(BN_NT), 0, st, (const E*)x, (const E*)residual,
+                       mean, invstd, gamma, beta, n_vec, C, relu, (E*)y);
   else
-    hipLaunchKernelGGL((k_bn_apply<false>), dim3(grid), dim3(BN_NT), 0, st, (const unsigned short*)x, nullptr, mean, invstd, gamma,
-                       beta, n_vec, C, relu, (unsigned short*)y);
+    hipLaunchKernelGGL((k_bn_apply<E, false>), dim3(grid), dim3(BN_NT), 0, st, (const E*)x, (const E*)nullptr, mean, invstd, gamma,
+                       beta, n_vec, C, relu, (E*)y);
   GLR_CHECK_LAUNCH();
   return GLR_OK;
+}
+
+template <typename E>
+int bn_bwd_launch(const void* x, const void* dy, const void* dy2, const void* y, const float* gamma, const float* beta,
+                  const float* mean, const float* invstd, long long R, int C, int relu, int has_residual, float* workspace,
+                  float* out4c, void* dx, void* dres, hipStream_t st) {
+  constexpr int UNA = 4 >> ElemTraits<E>::SHIFT;
+  static GlrOccupancy occ1, occ2;
+  const int res1 = bn_resident(occ1, (const void*)k_bn_reduce<E, 1, false>);
+  const int res2 = bn_resident(occ2, (const void*)k_bn_reduce<E, 1, true>);
+  const BnPlan pl = bn_plan(R, C, has_residual ? res2 : res1, 4 >> ElemTraits<E>::SHIFT);
+  const dim3 rgrid(pl.col_blocks, pl.n_part);
+  if (has_residual)
+    hipLaunchKernelGGL((k_bn_reduce<E, 1, true>), rgrid, dim3(BN_NT), 0, st, (const E*)x, (const E*)dy,
+                       (const E*)y, mean, invstd, gamma, beta, R, C, relu, pl.n_part, workspace,
+                       (E*)dres, (const E*)dy2);
+  else
+    hipLaunchKernelGGL((k_bn_reduce<E, 1, false>), rgrid, dim3(BN_NT), 0, st, (const E*)x, (const E*)dy,
+                       (const E*)nullptr, mean, invstd, gamma, beta, R, C, relu, pl.n_part, workspace, (E*)nullptr, (const E*)nullptr);
+  GLR_CHECK_LAUNCH();
+  hipLaunchKernelGGL((k_bn_finish<false>), dim3((C + 3) / 4), dim3(BN_NT), 0, st, workspace, pl.n_part, C, R, 0.f, 0.f, out4c,
+                     out4c + C, out4c + 2 * C, out4c + 3 * C, (long long*)nullptr);
+  GLR_CHECK_LAUNCH();
+  const long long n_vec = R * C / 8;
+  const int grid = (int)((n_vec + BN_NT * UNA - 1) / (BN_NT * UNA));
+  if (has_residual)
+    hipLaunchKernelGGL((k_bn_bwd_apply<E, true>), dim3(grid), dim3(BN_NT), 0, st, (const E*)x, (const E*)dres,
+                       mean, invstd, gamma, beta, out4c + 2 * C, out4c + 3 * C, n_vec, C, relu, (E*)dx);
+  else
+    hipLaunchKernelGGL((k_bn_bwd_apply<E, false>), dim3(grid), dim3(BN_NT), 0, st, (const E*)x, (const E*)dy,
+                       mean, invstd, gamma, beta, out4c + 2 * C, out4c + 3 * C, n_vec, C, relu, (E*)dx);
+  GLR_CHECK_LAUNCH();
+  return GLR_OK;
+}
+
+extern "C" int glr_bn_act_fwd(const void* x, const void* residual, const float* gamma, const float* beta, long long R,
+                              int C, float eps, float momentum, int relu, float* run_mean, float* run_var,
+                              long long* num_batches_tracked, float* mean, float* invstd, float* workspace, void* y,
+                              int dtype, void* stream) {
+  if (!x || !gamma || !beta || !mean || !invstd || !workspace || !y || !bn_shape_ok(R, C)) return GLR_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == GLR_BF16)
+    return bn_fwd_launch<unsigned short>(x, residual, gamma, beta, R, C, eps, momentum, relu, run_mean, run_var,
+                                         num_batches_tracked, mean, invstd, workspace, y, st);
+  if (dtype == GLR_F32)
+    return bn_fwd_launch<float>(x, residual, gamma, beta, R, C, eps, momentum, relu, run_mean, run_var, num_batches_tracked,
+                                mean, invstd, workspace, y, st);
+  return GLR_EDTYPE;
 }
 
 // out4c = [dgamma | dbeta | mean(dz) | mean(dz xhat)], 4*C floats.  has_residual: `y` (the forward's output) gives
 // the ReLU mask and `dres` receives the masked gradient (the skip connection's gradient).
 extern "C" int glr_bn_act_bwd(const void* x, const void* dy, const void* dy2, const void* y, const float* gamma, const float* beta,
                               const float* mean, const float* invstd, long long R, int C, int relu, int has_residual,
-                              float* workspace, float* out4c, void* dx, void* dres, void* stream) {
+                              float* workspace, float* out4c, void* dx, void* dres, int dtype, void* stream) {
   if (!x || !dy || !gamma || !beta || !mean || !invstd || !workspace || !out4c || !dx || !bn_shape_ok(R, C) ||
       (has_residual && (!y || !dres)) || (dy2 && !has_residual))
     return GLR_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-  static GlrOccupancy occ1, occ2;
-  const int res1 = bn_resident(occ1, (const void*)k_bn_reduce<1, false>);
-  const int res2 = bn_resident(occ2, (const void*)k_bn_reduce<1, true>);
-  const BnPlan pl = bn_plan(R, C, has_residual ? res2 : res1, 4);
-  const dim3 rgrid(pl.col_blocks, pl.n_part);
-  if (has_residual)
-    hipLaunchKernelGGL((k_bn_reduce<1, true>), rgrid, dim3(BN_NT), 0, st, (const unsigned short*)x, (const unsigned short*)dy,
-                       (const unsigned short*)y, mean, invstd, gamma, beta, R, C, relu, pl.n_part, workspace,
-                       (unsigned short*)dres, (const unsigned short*)dy2);
-  else
-    hipLaunchKernelGGL((k_bn_reduce<1, false>), rgrid, dim3(BN_NT), 0, st, (const unsigned short*)x, (const unsigned short*)dy,
-                       nullptr, mean, invstd, gamma, beta, R, C, relu, pl.n_part, workspace, nullptr, nullptr);
-  GLR_CHECK_LAUNCH();
-  hipLaunchKernelGGL((k_bn_finish<false>), dim3((C + 3) / 4), dim3(BN_NT), 0, st, workspace, pl.n_part, C, R, 0.f, 0.f, out4c,
-                     out4c + C, out4c + 2 * C, out4c + 3 * C, (long long*)nullptr);
-  GLR_CHECK_LAUNCH();
-  const long long n_vec = R * C / 8;
-  const int grid = (int)((n_vec + BN_NT * 4 - 1) / (BN_NT * 4));
-  if (has_residual)
-    hipLaunchKernelGGL((k_bn_bwd_apply<true>), dim3(grid), dim3(BN_NT), 0, st, (const unsigned short*)x, (const unsigned short*)dres,
-                       mean, invstd, gamma, beta, out4c + 2 * C, out4c + 3 * C, n_vec, C, relu, (unsigned short*)dx);
-  else
-    hipLaunchKernelGGL((k_bn_bwd_apply<false>), dim3(grid), dim3(BN_NT), 0, st, (const unsigned short*)x, (const unsigned short*)dy,
-                       mean, invstd, gamma, beta, out4c + 2 * C, out4c + 3 * C, n_vec, C, relu, (unsigned short*)dx);
-  GLR_CHECK_LAUNCH();
-  return GLR_OK;
+  if (dtype == GLR_BF16)
+    return bn_bwd_launch<unsigned short>(x, dy, dy2, y, gamma, beta, mean, invstd, R, C, relu, has_residual, workspace, out4c, dx,
+                                         dres, st);
+  if (dtype == GLR_F32)
+    return bn_bwd_launch<float>(x, dy, dy2, y, gamma, beta, mean, invstd, R, C, relu, has_residual, workspace, out4c, dx, dres, st);
+  return GLR_EDTYPE;
 }
 
 // ------------------------------------------------------------------------------------------

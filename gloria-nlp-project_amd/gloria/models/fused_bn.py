@@ -1,11 +1,12 @@
-"""BatchNorm2d (+ residual add) (+ ReLU) as ONE pair of HBM passes per direction on channels-last bf16 activations
+"""BatchNorm2d (+ residual add) (+ ReLU) as ONE pair of HBM passes per direction on channels-last bf16 (or fp32) activations
 (include/glr.h: glr_bn_act_fwd / glr_bn_act_bwd) for the 53 normalisation sites of the ResNet-50 image encoder
 (reference: torchvision's Bottleneck through /root/reference/gloria/models/cnn_backbones.py:31-35).
 
 Same parameters, buffers and state_dict keys as nn.BatchNorm2d: `fused_bn_act` is called WITH the nn.BatchNorm2d
-module.  The kernels cover what the training step runs (GPU, bf16 autocast, channels-last, training mode, power-of-two
-channel counts); every other case (fp32 parity mode, eval mode, NCHW, CPU tensors of the host-logic tests) is torch's
-own BatchNorm + add + relu - the same operator from the library, not a CPU fallback of the loss path.
+module.  The kernels cover what the training step runs (GPU, channels-last, training mode, power-of-two channel counts;
+bf16 under autocast and - since the end of round 3 - fp32, the parity configuration of BASELINE config 1); every other
+case (eval mode, NCHW, CPU tensors of the host-logic tests) is torch's own BatchNorm + add + relu - the same operator
+from the library, not a CPU fallback of the loss path.
 `GLR_FUSED_BN=0` switches the kernels off (A/B measurements)."""
 
 import os
@@ -49,7 +50,7 @@ class _BNAct(torch.autograd.Function):
         ws = _workspace(dev, R, c)
         N.check(L.glr_bn_act_fwd(N.ptr(x), N.ptr(residual), N.ptr(weight), N.ptr(bias), R, c, float(eps), float(momentum),
                                  1 if relu else 0, N.ptr(run_mean), N.ptr(run_var), N.ptr(nbt), stats.data_ptr(), stats.data_ptr() + 4 * c,
-                                 N.ptr(ws), N.ptr(y), N.stream()), "glr_bn_act_fwd")
+                                 N.ptr(ws), N.ptr(y), N.dtype_code(x.dtype), N.stream()), "glr_bn_act_fwd")
         ctx.save_for_backward(x, y if residual is not None else None, weight, bias, stats)
         ctx.relu, ctx.has_res = bool(relu), residual is not None
         if fork:
@@ -70,10 +71,10 @@ class _BNAct(torch.autograd.Function):
         n, c, h, w = x.shape
         R = n * h * w
         dev = x.device
-        if dy.dtype != torch.bfloat16 or not dy.is_contiguous(memory_format=torch.channels_last):
-            dy = dy.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
-        if dy2 is not None and (dy2.dtype != torch.bfloat16 or not dy2.is_contiguous(memory_format=torch.channels_last)):
-            dy2 = dy2.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        if dy.dtype != x.dtype or not dy.is_contiguous(memory_format=torch.channels_last):
+            dy = dy.to(x.dtype).contiguous(memory_format=torch.channels_last)
+        if dy2 is not None and (dy2.dtype != x.dtype or not dy2.is_contiguous(memory_format=torch.channels_last)):
+            dy2 = dy2.to(x.dtype).contiguous(memory_format=torch.channels_last)
         if dy2 is not None and not ctx.has_res:
             dy, dy2 = dy + dy2, None
         dx = torch.empty_like(x)
@@ -82,7 +83,7 @@ class _BNAct(torch.autograd.Function):
         ws = _workspace(dev, R, c)
         N.check(L.glr_bn_act_bwd(N.ptr(x), N.ptr(dy), N.ptr(dy2), N.ptr(y), N.ptr(weight), N.ptr(bias), stats.data_ptr(), stats.data_ptr() + 4 * c,
                                  R, c, 1 if ctx.relu else 0, 1 if ctx.has_res else 0, N.ptr(ws), N.ptr(out), N.ptr(dx),
-                                 N.ptr(dres), N.stream()), "glr_bn_act_bwd")
+                                 N.ptr(dres), N.dtype_code(x.dtype), N.stream()), "glr_bn_act_bwd")
         return dx, dres, out[0], out[1], None, None, None, None, None, None, None
 
 
@@ -90,11 +91,12 @@ def _fusable(bn, x, residual):
     c = x.shape[1] if x.dim() == 4 else 0
     # exactly nn.BatchNorm2d: SyncBatchNorm (Trainer(sync_bn=True)) has the same attributes but its statistics span the
     # process group - the per-rank kernels would silently turn the global-batch parity mode into per-rank BN
-    return (type(bn) is torch.nn.BatchNorm2d and ENABLED and x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4 and bn.training and bn.affine
+    return (type(bn) is torch.nn.BatchNorm2d and ENABLED and x.is_cuda and x.dtype in (torch.bfloat16, torch.float32) and x.dim() == 4
+            and bn.training and bn.affine
             and bn.track_running_stats and bn.momentum is not None and 8 <= c <= 2048 and (c & (c - 1)) == 0
             and bn.weight.dtype == torch.float32 and bn.bias.dtype == torch.float32
             and x.is_contiguous(memory_format=torch.channels_last)
-            and (residual is None or (residual.dtype == torch.bfloat16 and residual.shape == x.shape
+            and (residual is None or (residual.dtype == x.dtype and residual.shape == x.shape
                                       and residual.is_contiguous(memory_format=torch.channels_last))))
 
 

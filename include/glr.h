@@ -357,7 +357,8 @@ int glr_upsample_bilinear_cl(const float* x, long long sn, long long sc, long lo
  * Fused training-mode BatchNorm2d (+ residual add) (+ ReLU) on channels-last bf16 activations: the 53 normalisation
  * sites of the ResNet-50 image encoder (reference: torchvision resnet50 through
  * gloria/models/cnn_backbones.py:31-35, vision_model.py:67-86).  x / y / dy / dx / residual / dres: bf16
- * [R = N*H*W, C] (NHWC memory), C a power of two in [8, 2048].
+ * [R = N*H*W, C] (NHWC memory), C a power of two in [8, 2048]; `dtype` GLR_BF16 (the training configuration) or GLR_F32 (the
+ * fp32 parity configuration) is the element type of x / residual / y / dy / dy2 / dx / dres.
  *   fwd   mean, invstd [C] out (batch statistics, biased variance + eps); run_mean / run_var updated with
  *         `momentum` and the unbiased variance like nn.BatchNorm2d (NULL = no running statistics); num_batches_tracked
  *         (int64 scalar, NULL = none) is incremented by the same launch;
@@ -371,10 +372,10 @@ int glr_upsample_bilinear_cl(const float* x, long long sn, long long sc, long lo
 int glr_bn_workspace_floats(long long R, int C);
 int glr_bn_act_fwd(const void* x, const void* residual, const float* gamma, const float* beta, long long R, int C,
                    float eps, float momentum, int relu, float* run_mean, float* run_var, long long* num_batches_tracked,
-                   float* mean, float* invstd, float* workspace, void* y, void* stream);
+                   float* mean, float* invstd, float* workspace, void* y, int dtype, void* stream);
 int glr_bn_act_bwd(const void* x, const void* dy, const void* dy2, const void* y, const float* gamma, const float* beta, const float* mean,
                    const float* invstd, long long R, int C, int relu, int has_residual, float* workspace, float* out4c,
-                   void* dx, void* dres, void* stream);
+                   void* dx, void* dres, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Fused  y = LayerNorm(dropout(h) + inp)  of the BERT sub-layer outputs (reference: transformers'
