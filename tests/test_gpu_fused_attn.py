@@ -109,3 +109,50 @@ def test_attention_op_in_bert_matches_sdpa(monkeypatch):
         if gb[n].norm() > 1e-6 and not n.endswith("key.bias"):
             rel = float((ga[n] - gb[n]).norm() / gb[n].norm())
             assert rel < 6e-2, (n, rel)
+
+
+def test_dropout_hash_statistics():
+    """The attention kernel draws its keep bits from a keyed counter hash (two rounds of a 32-bit multiply-xorshift
+    mixer, 16 bits per score), not from Philox like the LayerNorm epilogue.  Beyond the Bernoulli rate: at p = 0.1 / 0.5 /
+    0.9 the rate is within 5 sigma, and at p = 0.5 (every bit a fair coin) neighbouring bits are uncorrelated along keys,
+    along queries, across heads, across sentences and across consecutive generator offsets (= consecutive training steps and
+    sites), the per-row and per-column keep counts have binomial spread, and no two rows of a head repeat."""
+    from gloria import _native as N
+    B, nh, L, H = 8, 12, 128, 768
+    g = torch.Generator().manual_seed(5)
+    q, k, v = ((torch.randn(B, L, H, generator=g)).to(DEV).bfloat16() for _ in range(3))
+    Lb = N.lib()
+
+    def bits(p, seed, off):
+        o = torch.empty_like(q)
+        lse = torch.empty(B * nh, 128, device=DEV)
+        keep = torch.zeros(B * nh, 128, 4, dtype=torch.int32, device=DEV)
+        N.check(Lb.glr_attn_fwd(N.ptr(q), N.ptr(k), N.ptr(v), None, B, nh, L, H, H, 0.125, p, seed, off, None, N.ptr(o), N.ptr(lse),
+                                N.ptr(keep), N.stream()), "fwd")
+        return _decode_keep(keep, B, nh, L).numpy()                         # [B, nh, L, L] bool
+
+    n = B * nh * L * L
+    for p in (0.1, 0.5, 0.9):
+        rate = bits(p, 1234, 8).mean()
+        assert abs(rate - (1 - p)) < 5 * (p * (1 - p) / n) ** 0.5, (p, rate)
+    a = bits(0.5, 1234, 8).astype(np.float64) * 2 - 1                      # +-1 coins
+    tol = 5 / np.sqrt(n)
+
+    def corr(x, y):
+        return float((x * y).mean())
+    assert abs(corr(a[..., :-1], a[..., 1:])) < tol                         # neighbouring keys
+    assert abs(corr(a[:, :, :-1, :], a[:, :, 1:, :])) < tol                 # neighbouring queries
+    assert abs(corr(a[:, :-1], a[:, 1:])) < tol                             # neighbouring heads
+    assert abs(corr(a[:-1], a[1:])) < tol                                   # neighbouring sentences
+    assert abs(corr(a[..., :-32], a[..., 32:])) < tol                       # the 32-key stride of the kernel's lane layout
+    for off in (12, 16, 8 + 4 * 36):                                        # next site, the one after, the next step
+        assert abs(corr(a, bits(0.5, 1234, off).astype(np.float64) * 2 - 1)) < tol, off
+    assert abs(corr(a, bits(0.5, 1235, 8).astype(np.float64) * 2 - 1)) < tol          # another seed
+    # keep counts per query row / per key column: binomial(128, 0.5) spread (variance 32)
+    for axis in (-1, -2):
+        cnt = (a > 0).sum(axis).astype(np.float64)
+        assert abs(cnt.var() / 32.0 - 1.0) < 0.05, (axis, cnt.var())
+    rows = (a > 0).reshape(B * nh, L, L)
+    packed = np.packbits(rows, axis=-1)
+    for h in range(0, B * nh, 7):
+        assert len({r.tobytes() for r in packed[h]}) == L                   # no repeated mask row inside a head
