@@ -156,25 +156,37 @@ struct Quant {
     // loop-invariant half of the compiler's own fp32 division (v_rcp_f32 + one Newton step), see quotient()
     const float y = __builtin_amdgcn_rcpf(range);
     rcp = __builtin_fmaf(__builtin_fmaf(-range, y, 1.0f), y, y);
+    // max == min: the reference divides 0 / 0 -> NaN -> uint8 cast; defined as grey level 0 here.  With range 1 and a
+    // zero reciprocal every quotient below is exactly 0 without a per-pixel test.
+    if (!(range > 0.f)) { range = 1.f; rcp = 0.f; }
   }
-  // n / range, bit-identical to the `/` operator.  For 8/16-bit sources n and range are integers below 2^17, so
-  // the v_div_scale / v_div_fixup steps of the compiler's expansion are identities and the division reduces to its
-  // fma chain with the reciprocal hoisted out of the per-pixel path (5 instructions instead of 13).
+  // n / range, bit-identical to the `/` operator.  For 8/16-bit sources n and range are INTEGERS with
+  // 0 <= n <= range < 2^17: the v_div_scale / v_div_fixup steps of the compiler's expansion are identities, and of its
+  // two residual corrections ONE already lands on the correctly rounded quotient - checked EXHAUSTIVELY for every such
+  // pair (glr_selftest_quotient, tests/test_gpu_collate.py): 3 instructions with the reciprocal hoisted instead of 13.
   __device__ __forceinline__ float quotient(float n) const {
     if (!IsIntSrc<T>::value) return div_(n, range);
     const float q0 = mul_(n, rcp);
     const float e0 = __builtin_fmaf(-range, q0, n);
-    const float q1 = __builtin_fmaf(e0, rcp, q0);
-    const float e1 = __builtin_fmaf(-range, q1, n);
-    return __builtin_fmaf(e1, rcp, q1);
+    return __builtin_fmaf(e0, rcp, q0);
   }
-  __device__ __forceinline__ float operator()(T raw) const {
-    if (!MINMAX) return (float)raw;                       // already the 8-bit image
-    float y = mul_(quotient(sub_((float)raw, mn)), 255.0f);
-    int q = (int)y;                                       // C cast: truncation (NaN when max == min -> 0)
-    q = y != y ? 0 : min(max(q, 0), 255);
-    return (float)q;
+  // ((x - min) / (max - min)) * 255 in fp32, before the C cast
+  __device__ __forceinline__ float scaled(T raw) const { return mul_(quotient(sub_((float)raw, mn)), 255.0f); }
+  // the 8-bit grey level of a raw pixel: the C cast (truncation) of scaled()
+  __device__ __forceinline__ int level(T raw) const {
+    if (!MINMAX) return (int)raw;                          // already the 8-bit image
+    const float y = scaled(raw);
+    int q = (int)y;
+    if (!IsIntSrc<T>::value) q = y != y ? 0 : q;          // float sources may hold NaN pixels; integer ones cannot
+    return min(max(q, 0), 255);
   }
+  // level(raw) inserted as byte `sel` of `old`: floor (the values are >= 0: truncation) + v_cvt_pk_u8_f32, which
+  // saturates to [0, 255] and turns NaN into 0 - two instructions for the cast, both clamps, the shift and the or
+  __device__ __forceinline__ unsigned pack(T raw, unsigned sel, unsigned old) const {
+    if (!MINMAX) return old | ((unsigned)raw << (8 * sel));
+    return __builtin_amdgcn_cvt_pk_u8_f32(__builtin_floorf(scaled(raw)), sel, old);
+  }
+  __device__ __forceinline__ float operator()(T raw) const { return (float)level(raw); }
 };
 
 // one source row as the resampler sees it: quantised pixel `col` as a float
@@ -352,7 +364,7 @@ __global__ __launch_bounds__(256) void k_collate(const unsigned char* __restrict
               const T* e = reinterpret_cast<const T*>(&raw[u]);
               unsigned w[VEC / 4] = {};
 #pragma unroll
-              for (int j = 0; j < VEC; ++j) w[j / 4] |= (unsigned)(int)q(e[j]) << (8 * (j % 4));
+              for (int j = 0; j < VEC; ++j) w[j / 4] = q.pack(e[j], j % 4, w[j / 4]);
               unsigned* d = reinterpret_cast<unsigned*>(lds + where[u]);
 #pragma unroll
               for (int j = 0; j < VEC / 4; ++j) d[j] = w[j];
@@ -482,7 +494,29 @@ __global__ __launch_bounds__(256) void k_u8_to_tensor(const unsigned char* __res
   }
 }
 
+// exhaustive check of Quant::quotient's shortened division: every integer pair 0 <= n <= d, d in [d_lo, d_hi)
+__global__ __launch_bounds__(256) void k_selftest_quotient(int d_lo, int d_hi, unsigned long long* __restrict__ bad) {
+  const int d = d_lo + blockIdx.x;
+  if (d >= d_hi) return;
+  Quant<short, true> q;
+  q.set(0.f, (float)d);
+  unsigned long long n_bad = 0;
+  for (int n = threadIdx.x; n <= d; n += 256) {
+    const float a = q.quotient((float)n), b = div_((float)n, (float)d);
+    n_bad += __float_as_uint(a) != __float_as_uint(b);
+  }
+  if (n_bad) atomicAdd(bad, n_bad);
+}
+
 }  // namespace
+
+extern "C" int glr_selftest_quotient(int d_lo, int d_hi, uint64_t* bad, void* stream) {
+  if (!bad || d_lo < 1 || d_hi <= d_lo || d_hi > (1 << 17) + 1) return GLR_EINVAL;
+  hipLaunchKernelGGL(k_selftest_quotient, dim3(d_hi - d_lo), dim3(256), 0, static_cast<hipStream_t>(stream), d_lo, d_hi,
+                     reinterpret_cast<unsigned long long*>(bad));
+  GLR_CHECK_LAUNCH();
+  return GLR_OK;
+}
 
 extern "C" int glr_aug_geom(const uint8_t* src, uint8_t* dst, int B, int size, const int32_t* flip, const double* matrix,
                             void* stream) {

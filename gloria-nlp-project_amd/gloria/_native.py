@@ -89,6 +89,7 @@ SYMBOLS = {
     "glr_aug_geom": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "glr_aug_jitter": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "glr_u8_to_tensor": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "glr_selftest_quotient": (c_int, [c_int, c_int, c_void_p, c_void_p]),
     "glr_dual_ce_fwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "glr_dual_ce_bwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "glr_global_sim_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float, c_void_p, c_int,

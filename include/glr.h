@@ -479,6 +479,9 @@ int glr_collate_images(const void* src, const int64_t* offset, const int32_t* de
 int glr_aug_geom(const uint8_t* src, uint8_t* dst, int B, int size, const int32_t* flip, const double* matrix, void* stream);
 int glr_aug_jitter(uint8_t* img, int B, int size, const int32_t* kind, const float* alpha, uint64_t* sums_ws, void* stream);
 int glr_u8_to_tensor(const uint8_t* img, int B, int size, float* out, void* stream);
+/* diagnostic: *bad += number of integer pairs 0 <= n <= d, d in [d_lo, d_hi), d_hi <= 2^17 + 1, for which the collate kernel's
+ * shortened fp32 division differs from the `/` operator (*bad must be zeroed by the caller; expected to stay 0) */
+int glr_selftest_quotient(int d_lo, int d_hi, uint64_t* bad, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Optimisation step over FLAT parameter buffers (the reference delegates it to Lightning: Adam(betas=(0.5, 0.999)),
